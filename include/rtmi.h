@@ -1,0 +1,271 @@
+/*
+ * rtmi.h -- C ABI of librtmi.so, the MI355X-native per-pixel path tracer.
+ *
+ * This is the drop-in boundary for the reference's hot path
+ *     scene JSON  ->  render kernel  ->  float framebuffer  ->  PPM
+ * Every entry point names the reference interface it replaces.  Paths are
+ * relative to the reference checkout (gpu-version/ = CUDA renderer whose
+ * interface is kept, cmake-cpu-version/ = CPU renderer whose ray_color
+ * semantics are followed).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs; no C++/torch/HIP types.
+ *   - every function that can fail returns an rt_status (0 = RT_OK); the text
+ *     of the last failure on the calling thread is at rt_last_error().
+ *     The library never calls exit() (the reference does: rtweekend.cuh:41-53).
+ *   - framebuffer layout is the reference's: rgb_sum[(y*W + x)*3 + c] holds the
+ *     SUM over samples (not the mean), fp32, row y = 0 is the BOTTOM row
+ *     (gpu-version/main.cu:76-78,102-104); division by spp and gamma are the
+ *     writer's job (gpu-version/color.cuh:70-95).
+ *   - there is no CPU fallback: rt_render_* fail with RT_ERR_HIP when no
+ *     gfx950 device / runtime is usable.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_ARG = 1,     /* null / out-of-range argument                      */
+    RT_ERR_IO = 2,      /* file cannot be read / written                     */
+    RT_ERR_JSON = 3,    /* malformed JSON text                               */
+    RT_ERR_SCENE = 4,   /* well-formed JSON, invalid scene (unknown type...) */
+    RT_ERR_HIP = 5,     /* HIP runtime / device error                        */
+    RT_ERR_LIMIT = 6    /* scene does not fit the kernel's LDS staging       */
+} rt_status;
+
+/* ---- table records (what the scene flattens to; also what the checker in
+ *      tests/ reads back through rt_scene_get_*) ------------------------- */
+
+/* gpu-version/rtweekend.cuh:70-91 (enum class class_type) */
+typedef enum rt_prim_type {
+    RT_PRIM_SPHERE = 0,   /* object.cuh:40-94   f = {cx,cy,cz,radius}        */
+    RT_PRIM_XY_RECT = 1,  /* object.cuh:96-132  f = {x0,x1,y0,y1,k}          */
+    RT_PRIM_XZ_RECT = 2,  /* object.cuh:134-164 f = {x0,x1,z0,z1,k}          */
+    RT_PRIM_YZ_RECT = 3,  /* object.cuh:166-197 f = {y0,y1,z0,z1,k}          */
+    RT_PRIM_CYLINDER = 4  /* object.cuh:216-297 f = {radius,zmin,zmax}, m/m_inv */
+} rt_prim_type;
+
+typedef enum rt_mat_type {
+    RT_MAT_LAMBERTIAN = 0,    /* material.cuh:28-56   tex = albedo texture   */
+    RT_MAT_METAL = 1,         /* material.cuh:58-75   albedo, fuzz (<=1)     */
+    RT_MAT_DIELECTRIC = 2,    /* material.cuh:89-159  ir                     */
+    RT_MAT_DIFFUSE_LIGHT = 3  /* material.cuh:161-182 tex = emission texture */
+} rt_mat_type;
+
+typedef enum rt_tex_type {
+    RT_TEX_SOLID = 0,   /* texture.cuh:14-31  c0                             */
+    RT_TEX_CHECKER = 1  /* texture.cuh:33-57  c0 = even, c1 = odd            */
+} rt_tex_type;
+
+typedef struct rt_prim {
+    int32_t type;      /* rt_prim_type                                       */
+    int32_t material;  /* index into the material table                      */
+    float f[6];        /* per-type parameters, see rt_prim_type              */
+    float m[12];       /* cylinder object->world, rows of a 3x4 affine       */
+    float m_inv[12];   /* cylinder world->object                             */
+} rt_prim;
+
+typedef struct rt_material {
+    int32_t type;     /* rt_mat_type                                         */
+    int32_t texture;  /* lambertian / diffuse_light: texture index, else -1  */
+    float albedo[3];  /* metal                                               */
+    float fuzz;       /* metal, clamped to <= 1 (material.cuh:61)            */
+    float ir;         /* dielectric                                          */
+} rt_material;
+
+typedef struct rt_texture {
+    int32_t type;  /* rt_tex_type */
+    float c0[3];
+    float c1[3];
+} rt_texture;
+
+/* camera.cuh:9-29 constructor arguments + the derived frame the kernel uses */
+typedef struct rt_camera {
+    float lookfrom[3], lookat[3], vup[3];
+    float vfov;        /* degrees                                            */
+    float aspect;      /* width / height                                     */
+    float aperture;
+    float focus_dist;
+    /* derived (camera.cuh:18-28), computed in fp64 and rounded once          */
+    float origin[3], lower_left[3], horizontal[3], vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius;
+} rt_camera;
+
+/* scene-level switches for the deltas between the reference's two renderers
+ * (SURVEY.md appendix A). */
+#define RT_FLAG_SKY_GRADIENT 1u /* miss colour = cmake-cpu-version/main.cpp:36-38
+                                   lerp(white, (0.5,0.7,1)); else the JSON
+                                   "background" constant (main.cu:63)         */
+#define RT_FLAG_DEFOCUS_BLUR 2u /* camera.h:34 lens sampling on (the CUDA
+                                   renderer has it commented out,
+                                   camera.cuh:33-34)                          */
+
+typedef struct rt_scene_info {
+    int32_t width, height, samples_per_pixel, max_depth;
+    int32_t num_prims, num_materials, num_textures;
+    uint32_t flags;
+    float background[3];
+} rt_scene_info;
+
+typedef struct rt_scene rt_scene; /* opaque; gpu-version/parser.hpp:16-32 `struct scene` */
+
+/* ---- scene I/O -------------------------------------------------------- */
+
+/* parse_scene(filename), gpu-version/parser.hpp:504-573.  Same schema:
+ * background[3] max_depth samples_per_pixel width height
+ * camera{lookfrom lookat vup vfov aperture} object.data[] material.data[]
+ * texture.data[] [output_file].  Extensions: texture type "checker"
+ * {even[3], odd[3]} (texture.cuh:33-57 has the class, the parser lacks it),
+ * optional top-level "sky_gradient": bool and "defocus_blur": bool.
+ * Unknown object/material/texture "type" is a hard error (the reference
+ * silently leaves the slot uninitialised). Returns NULL on failure. */
+rt_scene *rt_scene_load_json(const char *path);
+rt_scene *rt_scene_parse_json(const char *text, size_t len);
+
+/* random_scene(), cmake-cpu-version/main.cpp:125-172 (and camera :89-94):
+ * checker ground + 22x22 jittered small spheres + 3 big ones, sky gradient,
+ * defocus blur, 16:9.  Randomness comes from Philox keyed by `seed`, drawn in
+ * the order the reference draws (choose_mat, cx, cz, then material draws). */
+rt_scene *rt_scene_rtiow(uint32_t seed, int width, int height, int spp, int max_depth);
+
+/* serialise to the JSON schema above (round-trips through rt_scene_parse_json).
+ * Returns bytes needed incl. NUL; writes at most cap bytes. */
+size_t rt_scene_to_json(const rt_scene *s, char *out, size_t cap);
+
+void rt_scene_free(rt_scene *s);
+
+/* ---- programmatic scene building: the constructor argument lists of the
+ *      reference classes (the C++ wrappers in rtmi.hpp call these) -------- */
+rt_scene *rt_scene_new(int width, int height, int spp, int max_depth);
+int rt_scene_set_background(rt_scene *s, const float rgb[3], uint32_t flags);
+/* camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist) camera.cuh:9-15;
+ * aspect <= 0 -> width/height, focus_dist <= 0 -> |lookfrom-lookat| (parser.hpp:122-124) */
+int rt_scene_set_camera(rt_scene *s, const float lookfrom[3], const float lookat[3],
+                        const float vup[3], float vfov, float aspect, float aperture,
+                        float focus_dist);
+int rt_scene_add_solid_color(rt_scene *s, const float rgb[3]);                 /* -> texture id */
+int rt_scene_add_checker(rt_scene *s, const float even[3], const float odd[3]); /* -> texture id */
+int rt_scene_add_lambertian(rt_scene *s, int texture);                         /* -> material id */
+int rt_scene_add_metal(rt_scene *s, const float albedo[3], float fuzz);
+int rt_scene_add_dielectric(rt_scene *s, float ir);
+int rt_scene_add_diffuse_light(rt_scene *s, int texture);
+int rt_scene_add_sphere(rt_scene *s, const float center[3], float radius, int material); /* -> prim id */
+/* axis: 0 = xy_rect (a=x,b=y,k=z), 1 = xz_rect, 2 = yz_rect */
+int rt_scene_add_rect(rt_scene *s, int axis, float a0, float a1, float b0, float b1, float k,
+                      int material);
+/* cylinder(radius, zmin, zmax, mat) then rotate(axis, degrees) then translate(offset),
+ * composed as parser.hpp:423-440 does (o2w = T * R); pass NULL to skip either. */
+int rt_scene_add_cylinder(rt_scene *s, float radius, float zmin, float zmax, int material,
+                          const float rot_axis[3], float rot_degrees, const float translate[3]);
+/* negative ids above = -rt_status */
+
+/* CLI overrides -w -h -spp -d (cmake-cpu-version/main.cpp:71-81); <= 0 keeps the
+ * value. Re-derives the camera when the aspect changes. */
+int rt_scene_override(rt_scene *s, int width, int height, int spp, int max_depth);
+
+/* ---- table read-back (host logic tests, checker input) ----------------- */
+int rt_scene_get_info(const rt_scene *s, rt_scene_info *out);
+int rt_scene_get_camera(const rt_scene *s, rt_camera *out);
+int rt_scene_get_prims(const rt_scene *s, rt_prim *out, int cap);         /* -> count */
+int rt_scene_get_materials(const rt_scene *s, rt_material *out, int cap); /* -> count */
+int rt_scene_get_textures(const rt_scene *s, rt_texture *out, int cap);   /* -> count */
+
+/* ---- render ------------------------------------------------------------ */
+
+typedef struct rt_opts {
+    uint64_t seed;       /* Philox key; the reference seeds curand with the pixel
+                            id (main.cu:120-125)                               */
+    int32_t device;      /* HIP device ordinal                                 */
+    /* row-tile shard (multi-GPU): this call renders the row tiles
+     *   t = tile_first, tile_first + tile_stride, ...   (< ceil(H / tile_rows))
+     * tile t covers image rows [t*tile_rows, min(H,(t+1)*tile_rows)).
+     * tile_stride <= 1 and tile_first == 0 -> whole image.                   */
+    int32_t tile_rows;   /* 0 -> 8                                             */
+    int32_t tile_first;
+    int32_t tile_stride;
+    /* samples are summed in chunks of spp_chunk (each chunk in sample order by
+     * one work-item, chunk sums added in chunk order); 0 -> one chunk = all spp,
+     * i.e. the reference's plain in-order sum (main.cu:95-101).               */
+    int32_t spp_chunk;
+    int32_t sample_first; /* render samples [sample_first, sample_first+count) */
+    int32_t sample_count; /* 0 -> scene spp                                    */
+    uint32_t variant;     /* kernel variant selector, 0 = default (tuning A/B) */
+} rt_opts;
+
+typedef struct rt_stats {
+    double kernel_ms;     /* hipEvent time of the render launches of this call */
+    double upload_ms;     /* scene table upload                                */
+    int32_t launches;
+    int32_t local_rows;   /* rows rendered by this shard                       */
+    /* exact event counts, filled only by rt_render_hip_count */
+    uint64_t samples, queries, prim_tests, hits, misses;
+    uint64_t scatter[4];  /* per rt_mat_type */
+    uint64_t rng_draws;
+} rt_stats;
+
+void rt_opts_default(rt_opts *o);
+
+/* number of image rows / floats a shard owns (dense local buffer:
+ * local row r <-> global row rt_shard_row(...)). */
+int rt_shard_rows(const rt_scene *s, const rt_opts *o);
+int rt_shard_global_row(const rt_scene *s, const rt_opts *o, int local_row);
+
+/* render<<<grid, 8x8>>>(spp, background, cam, world, max_depth, W, H, image, states)
+ * gpu-version/main.cu:72-105 with its launch at :505-507.
+ * d_rgb_sum: DEVICE pointer, rt_shard_rows()*W*3 floats, local rows dense.
+ * stream: hipStream_t as void* (NULL = default stream). Asynchronous when
+ * stats == NULL; with stats it records hipEvents and synchronises the stream. */
+int rt_render_hip_device(const rt_scene *s, const rt_opts *o, void *d_rgb_sum, void *stream,
+                         rt_stats *stats);
+
+/* same, host buffer in / out: allocates, launches, copies back, frees
+ * (main.cu:482-513: cudaMallocManaged + render + cudaDeviceSynchronize). */
+int rt_render_hip(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats *stats);
+
+/* diagnostic launch of the same kernel with exact event counters (samples,
+ * hit queries, primitive tests, ...) for the roofline's algorithmic flops.
+ * rgb_sum may be NULL. */
+int rt_render_hip_count(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats *stats);
+
+/* scatter a shard's dense local rows into a full-image buffer (host side of
+ * the multi-GPU gather; also used after the RCCL gather on the root). */
+int rt_shard_scatter_rows(const rt_scene *s, const rt_opts *o, const float *local_rgb,
+                          float *full_rgb);
+
+/* ---- output ------------------------------------------------------------ */
+
+/* output_image(), gpu-version/main.cu:359-372 + write_color color.cuh:70-95:
+ * "P3\n%d %d\n255\n" then "%d %d %d\n" per pixel, rows top to bottom,
+ * value = int(256 * clamp(sqrt(sum/spp), 0, 0.999)). */
+int rt_write_ppm(const char *path, const float *rgb_sum, int width, int height, int spp);
+/* the same quantisation into a caller buffer of width*height*3 bytes, rows top
+ * to bottom; gamma = 0 gives write_image()'s linear bytes (color.cuh:15-35). */
+int rt_quantize_rgb8(const float *rgb_sum, int width, int height, int spp, int gamma,
+                     uint8_t *out);
+
+/* ---- misc -------------------------------------------------------------- */
+const char *rt_last_error(void);
+const char *rt_status_string(int status);
+int rt_abi_version(void);
+/* number of usable gfx950 devices, or -rt_status */
+int rt_device_count(void);
+/* Philox4x32-10 block (the stream the kernel draws from), for known-answer tests */
+void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* slab test, gpu-version/aabb.hpp:15-29 (host evaluation of the device helper's formula) */
+int rt_aabb_hit(const float bmin[3], const float bmax[3], const float orig[3], const float dir[3],
+                float t_min, float t_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

@@ -1,0 +1,67 @@
+// Device-side scene image shared between the host packer (render_hip.hip, host
+// part) and the kernel.  One contiguous buffer, 16-byte records:
+//
+//   HOT part (copied into LDS by every workgroup; everything the primitive loop reads)
+//     sphere  [ns]  1 x float4   {cx, cy, cz, r*r}
+//     rect    [nr]  2 x float4   {a0, a1, b0, b1} {k, axis(bits), 0, 0}
+//     cyl     [nc]  4 x float4   m_inv rows 0..2, {radius^2, zmin, zmax, 0}
+//   COLD part (stays in global memory / L2; read once per bounce by the winning lane)
+//     sphere  [ns]  1 x float4   {1/r, material(bits), list index(bits), 0}
+//     rect    [nr]  1 x float4   {material(bits), list index(bits), 0, 0}
+//     cyl     [nc]  4 x float4   m rows 0..2, {material(bits), list index(bits), 0, 0}
+//     mat     [nm]  3 x float4   {kind(bits), p0, p1, p2} {c0.xyz, p3} {c1.xyz, 0}
+//
+// Primitives are grouped by type (spheres, rects, cylinders), each group in list
+// order; the original list index is kept for the reference's tie rule (a later
+// object replaces an earlier one at equal t: hittable_list::hit accepts
+// root <= closest_so_far, gpu-version/object.cuh:23-37 with :61).
+#pragma once
+#include <stdint.h>
+
+namespace rtmi {
+
+enum MatKind : int32_t {
+    MK_LAMBERT_SOLID = 0,    // c0 = albedo
+    MK_LAMBERT_CHECKER = 1,  // c0 = even, c1 = odd
+    MK_METAL = 2,            // c0 = albedo, p0 = fuzz
+    MK_DIELECTRIC = 3,       // p0 = ir, p1 = 1/ir, p2 = r0(1/ir), p3 = r0(ir)
+    MK_LIGHT_SOLID = 4,      // c0 = emission
+    MK_LIGHT_CHECKER = 5     // c0 = even, c1 = odd
+};
+
+struct DevCamera {
+    float origin[3], lower_left[3], horizontal[3], vertical[3], u[3], v[3];
+    float lens_radius;
+};
+
+// kernel parameter block (passed by value: lands in SGPRs / the kernarg segment)
+struct RenderParams {
+    DevCamera cam;
+    float background[3];
+    uint32_t flags;
+    int32_t width, height, max_depth;
+    // shard geometry (see rt_opts)
+    int32_t tile_rows, tile_first, tile_stride, num_tiles, local_rows;
+    // samples
+    int32_t sample_first, sample_count, spp_chunk, num_chunks;
+    uint32_t seed_lo, seed_hi;
+    // scene image
+    int32_t ns, nr, nc, nm;
+    int32_t hot_vec4;        // float4 count of the hot part (LDS bytes / 16)
+    int32_t off_rect_hot;    // float4 offsets inside the image
+    int32_t off_cyl_hot;
+    int32_t off_sph_cold;
+    int32_t off_rect_cold;
+    int32_t off_cyl_cold;
+    int32_t off_mat;
+    int32_t blocks_x;        // workgroups per row band
+    int32_t bands;           // 8-row bands in the shard
+};
+
+struct DevCounters {
+    unsigned long long samples, queries, prim_tests, hits, misses;
+    unsigned long long scatter[4];
+    unsigned long long rng_draws;
+};
+
+}  // namespace rtmi

@@ -1,0 +1,60 @@
+// Philox4x32-10 counter-based RNG (Salmon et al., SC'11), host + device.
+//
+// Replaces the reference's per-pixel curand XORWOW state (48 B/pixel in global
+// memory, gpu-version/main.cu:120-125, 487-496) with a stateless stream:
+//     key     = (seed_lo, seed_hi)
+//     counter = (pixel_id, sample_index, block_index, 0)
+// and draw n of a sample is word n%4 of block n/4.  A uniform is the top 24
+// bits, xi = (word >> 8) * 2^-24 in [0,1), exactly representable in fp32 and
+// fp64, which is what lets the compiled fp64 reference (oracle/_ref) consume
+// the identical stream through its rand() hook.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RTMI_HD __host__ __device__ __forceinline__
+#else
+#define RTMI_HD inline
+#endif
+
+namespace rtmi {
+
+struct Philox4 {
+    uint32_t v[4];
+};
+
+RTMI_HD uint32_t philox_mulhi(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+RTMI_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                              uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = philox_mulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = philox_mulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += W0;
+        k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0;
+    o.v[1] = c1;
+    o.v[2] = c2;
+    o.v[3] = c3;
+    return o;
+}
+
+}  // namespace rtmi

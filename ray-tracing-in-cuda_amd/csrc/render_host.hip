@@ -1,0 +1,496 @@
+// Host side of the render path: packs the scene tables into the device image
+// (device_scene.h), keeps it resident per device, computes the shard geometry and
+// launches render_kernel.  Replaces jsonmain()'s device set-up, gpu-version/main.cu:
+// 462-513 (move_to_device<<<1,1>>>, cudaMallocManaged framebuffer, curand state
+// allocation + init_random_library<<<W*H,1>>>, render<<<>>>, cudaDeviceSynchronize):
+// one hipMemcpy of a few KB replaces the object-graph rebuild, and there is no RNG
+// state to allocate or initialise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "device_scene.h"
+#include "scene.hpp"
+
+namespace rtmi {
+
+void launch_render(const RenderParams &P, const void *image, float *out, DevCounters *counters, size_t lds_bytes,
+                   unsigned grid, hipStream_t stream);
+void launch_reduce(const float *partial, float *out, size_t plane, int num_chunks, hipStream_t stream);
+int set_max_dynamic_lds(size_t bytes);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_error("HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+            return RT_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+struct DeviceEntry {
+    int device = -1;
+    uint64_t version = 0;
+    void *d_image = nullptr;
+    size_t image_bytes = 0;
+    float *d_partial = nullptr;
+    size_t partial_bytes = 0;
+    DevCounters *d_counters = nullptr;
+};
+
+struct DeviceSceneCache {
+    std::mutex mu;
+    std::vector<DeviceEntry> entries;
+    // host-side packed image (rebuilt when the scene version changes)
+    uint64_t packed_version = 0;
+    std::vector<float> image;  // float4 records
+    RenderParams layout;       // ns/nr/nc/nm + offsets filled by pack
+    ~DeviceSceneCache() {
+        int cur = 0;
+        bool have = hipGetDevice(&cur) == hipSuccess;
+        for (DeviceEntry &e : entries) {
+            if (e.device < 0) continue;
+            if (hipSetDevice(e.device) != hipSuccess) continue;
+            if (e.d_image) (void)hipFree(e.d_image);
+            if (e.d_partial) (void)hipFree(e.d_partial);
+            if (e.d_counters) (void)hipFree(e.d_counters);
+        }
+        if (have) (void)hipSetDevice(cur);
+    }
+};
+
+static inline float bits(int32_t v) {
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+// ---- scene tables -> device image ------------------------------------------------
+static void pack_scene(const Scene &s, DeviceSceneCache &c) {
+    std::vector<int> sph, rec, cyl;
+    for (size_t i = 0; i < s.prims.size(); ++i) {
+        switch (s.prims[i].type) {
+        case RT_PRIM_SPHERE: sph.push_back((int)i); break;
+        case RT_PRIM_CYLINDER: cyl.push_back((int)i); break;
+        default: rec.push_back((int)i); break;
+        }
+    }
+    RenderParams &L = c.layout;
+    memset(&L, 0, sizeof L);
+    L.ns = (int)sph.size(), L.nr = (int)rec.size(), L.nc = (int)cyl.size(), L.nm = (int)s.mats.size();
+    int off = 0;
+    off += L.ns;  // sphere hot
+    L.off_rect_hot = off;
+    off += 2 * L.nr;
+    L.off_cyl_hot = off;
+    off += 4 * L.nc;
+    L.hot_vec4 = off;
+    L.off_sph_cold = off;
+    off += L.ns;
+    L.off_rect_cold = off;
+    off += L.nr;
+    L.off_cyl_cold = off;
+    off += 4 * L.nc;
+    L.off_mat = off;
+    off += 3 * L.nm;
+    c.image.assign((size_t)(off > 0 ? off : 1) * 4, 0.0f);
+    float *I = c.image.data();
+    auto rec4 = [&](int idx) { return I + (size_t)idx * 4; };
+
+    for (int k = 0; k < L.ns; ++k) {
+        const rt_prim &p = s.prims[sph[k]];
+        float *h = rec4(k);
+        h[0] = p.f[0], h[1] = p.f[1], h[2] = p.f[2];
+        h[3] = p.f[3] * p.f[3];  // r*r in fp32, as sphere::hit evaluates it
+        float *cd = rec4(L.off_sph_cold + k);
+        cd[0] = 1.0f / p.f[3];   // (p - c) / r  ==  (1/r) * (p - c), vec3.cuh:105
+        cd[1] = bits(p.material);
+        cd[2] = bits(sph[k]);
+    }
+    for (int k = 0; k < L.nr; ++k) {
+        const rt_prim &p = s.prims[rec[k]];
+        float *h = rec4(L.off_rect_hot + 2 * k);
+        h[0] = p.f[0], h[1] = p.f[1], h[2] = p.f[2], h[3] = p.f[3];
+        h[4] = p.f[4];
+        h[5] = bits(p.type - RT_PRIM_XY_RECT);
+        float *cd = rec4(L.off_rect_cold + k);
+        cd[0] = bits(p.material);
+        cd[1] = bits(rec[k]);
+    }
+    for (int k = 0; k < L.nc; ++k) {
+        const rt_prim &p = s.prims[cyl[k]];
+        float *h = rec4(L.off_cyl_hot + 4 * k);
+        memcpy(h, p.m_inv, 12 * sizeof(float));
+        h[12] = p.f[0] * p.f[0], h[13] = p.f[1], h[14] = p.f[2];
+        float *cd = rec4(L.off_cyl_cold + 4 * k);
+        memcpy(cd, p.m, 12 * sizeof(float));
+        cd[12] = bits(p.material);
+        cd[13] = bits(cyl[k]);
+    }
+    for (int k = 0; k < L.nm; ++k) {
+        const rt_material &m = s.mats[k];
+        float *q = rec4(L.off_mat + 3 * k);
+        int kind = MK_LAMBERT_SOLID;
+        const rt_texture *t = (m.texture >= 0 && m.texture < (int)s.texs.size()) ? &s.texs[m.texture] : nullptr;
+        switch (m.type) {
+        case RT_MAT_LAMBERTIAN:
+        case RT_MAT_DIFFUSE_LIGHT: {
+            bool light = m.type == RT_MAT_DIFFUSE_LIGHT;
+            bool checker = t && t->type == RT_TEX_CHECKER;
+            kind = light ? (checker ? MK_LIGHT_CHECKER : MK_LIGHT_SOLID) : (checker ? MK_LAMBERT_CHECKER : MK_LAMBERT_SOLID);
+            if (t) {
+                q[4] = t->c0[0], q[5] = t->c0[1], q[6] = t->c0[2];
+                q[8] = t->c1[0], q[9] = t->c1[1], q[10] = t->c1[2];
+            }
+            break;
+        }
+        case RT_MAT_METAL:
+            kind = MK_METAL;
+            q[1] = m.fuzz;
+            q[4] = m.albedo[0], q[5] = m.albedo[1], q[6] = m.albedo[2];
+            break;
+        case RT_MAT_DIELECTRIC: {
+            kind = MK_DIELECTRIC;
+            float ir = m.ir, inv_ir = 1.0f / m.ir;
+            // reflectance()'s r0 for both refraction ratios, material.cuh:175-178
+            float r0f = (1.0f - inv_ir) / (1.0f + inv_ir);
+            r0f = r0f * r0f;
+            float r0b = (1.0f - ir) / (1.0f + ir);
+            r0b = r0b * r0b;
+            q[1] = ir, q[2] = inv_ir, q[3] = r0f, q[7] = r0b;
+            break;
+        }
+        default: break;
+        }
+        q[0] = bits(kind);
+    }
+    c.packed_version = s.version;
+}
+
+// ---- shard geometry ----------------------------------------------------------------
+struct Shard {
+    int tile_rows, tile_first, tile_stride, num_tiles, local_tiles, local_rows;
+};
+
+static int shard_of(const Scene &s, const rt_opts *o, Shard &sh) {
+    sh.tile_rows = (o && o->tile_rows > 0) ? o->tile_rows : 8;
+    sh.tile_first = o ? o->tile_first : 0;
+    sh.tile_stride = (o && o->tile_stride > 1) ? o->tile_stride : 1;
+    sh.num_tiles = (s.height + sh.tile_rows - 1) / sh.tile_rows;
+    if (sh.tile_first < 0 || (sh.tile_stride > 1 && sh.tile_first >= sh.tile_stride)) {
+        set_error("tile_first %d out of range for tile_stride %d", sh.tile_first, sh.tile_stride);
+        return RT_ERR_ARG;
+    }
+    sh.local_tiles = 0;
+    sh.local_rows = 0;
+    for (int t = sh.tile_first; t < sh.num_tiles; t += sh.tile_stride) {
+        int rows = s.height - t * sh.tile_rows;
+        if (rows > sh.tile_rows) rows = sh.tile_rows;
+        sh.local_rows += rows;
+        sh.local_tiles++;
+    }
+    return RT_OK;
+}
+
+static int shard_global_row(const Shard &sh, int local_row) {
+    int tl = local_row / sh.tile_rows;
+    return (sh.tile_first + tl * sh.tile_stride) * sh.tile_rows + (local_row - tl * sh.tile_rows);
+}
+
+}  // namespace rtmi
+
+using namespace rtmi;
+
+extern "C" {
+
+int rt_shard_rows(const rt_scene *s, const rt_opts *o) {
+    if (!s) return -RT_ERR_ARG;
+    Shard sh;
+    int rc = shard_of(s->s, o, sh);
+    return rc ? -rc : sh.local_rows;
+}
+
+int rt_shard_global_row(const rt_scene *s, const rt_opts *o, int local_row) {
+    if (!s) return -RT_ERR_ARG;
+    Shard sh;
+    int rc = shard_of(s->s, o, sh);
+    if (rc) return -rc;
+    if (local_row < 0 || local_row >= sh.local_rows) return -RT_ERR_ARG;
+    return shard_global_row(sh, local_row);
+}
+
+int rt_shard_scatter_rows(const rt_scene *s, const rt_opts *o, const float *local_rgb, float *full_rgb) {
+    if (!s || !local_rgb || !full_rgb) {
+        set_error("rt_shard_scatter_rows: null argument");
+        return RT_ERR_ARG;
+    }
+    Shard sh;
+    int rc = shard_of(s->s, o, sh);
+    if (rc) return rc;
+    const size_t row_floats = (size_t)s->s.width * 3;
+    for (int lr = 0; lr < sh.local_rows; ++lr)
+        memcpy(full_rgb + (size_t)shard_global_row(sh, lr) * row_floats, local_rgb + (size_t)lr * row_floats,
+               row_floats * sizeof(float));
+    return RT_OK;
+}
+
+int rt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return -RT_ERR_HIP;
+    }
+    return n;
+}
+
+static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, void *stream_v, rt_stats *stats,
+                       bool count) {
+    if (!sc || !d_rgb_sum) {
+        set_error("rt_render_hip_device: null scene or output pointer");
+        return RT_ERR_ARG;
+    }
+    const Scene &s = sc->s;
+    int rc = scene_validate(s);
+    if (rc) return rc;
+    Shard sh;
+    rc = shard_of(s, o, sh);
+    if (rc) return rc;
+    if (stats) {
+        double keep = 0;
+        (void)keep;
+        memset(stats, 0, sizeof *stats);
+        stats->local_rows = sh.local_rows;
+    }
+    if (sh.local_rows == 0) return RT_OK;
+
+    int sample_first = o ? o->sample_first : 0;
+    int sample_count = (o && o->sample_count > 0) ? o->sample_count : s.spp;
+    int spp_chunk = (o && o->spp_chunk > 0 && o->spp_chunk < sample_count) ? o->spp_chunk : sample_count;
+    int num_chunks = (sample_count + spp_chunk - 1) / spp_chunk;
+    if (sample_first < 0) {
+        set_error("sample_first must be >= 0");
+        return RT_ERR_ARG;
+    }
+
+    int device = o ? o->device : 0;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) {
+        set_error("no HIP device visible: the render path has no CPU fallback");
+        return RT_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("device %d out of range (%d visible)", device, ndev);
+        return RT_ERR_ARG;
+    }
+    int prev_device = 0;
+    HIP_TRY(hipGetDevice(&prev_device));
+    if (prev_device != device) HIP_TRY(hipSetDevice(device));
+    struct Restore {
+        int prev, cur;
+        ~Restore() {
+            if (prev != cur) (void)hipSetDevice(prev);
+        }
+    } restore{prev_device, device};
+
+    hipStream_t stream = (hipStream_t)stream_v;
+
+    // ---- resident scene image
+    Scene &ms = const_cast<Scene &>(s);
+    if (!ms.dev) ms.dev = std::make_shared<DeviceSceneCache>();
+    DeviceSceneCache &cache = *ms.dev;
+    std::lock_guard<std::mutex> lock(cache.mu);
+    if (cache.packed_version != s.version) pack_scene(s, cache);
+    DeviceEntry *ent = nullptr;
+    for (DeviceEntry &e : cache.entries)
+        if (e.device == device) ent = &e;
+    if (!ent) {
+        cache.entries.emplace_back();
+        ent = &cache.entries.back();
+        ent->device = device;
+    }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    if (stats) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventCreate(&ev2));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    size_t image_bytes = cache.image.size() * sizeof(float);
+    if (ent->version != s.version || !ent->d_image) {
+        if (ent->image_bytes < image_bytes) {
+            if (ent->d_image) HIP_TRY(hipFree(ent->d_image));
+            ent->d_image = nullptr;
+            HIP_TRY(hipMalloc(&ent->d_image, image_bytes));
+            ent->image_bytes = image_bytes;
+        }
+        // the image must be complete before any stream may read it; scenes are a few KB
+        HIP_TRY(hipMemcpy(ent->d_image, cache.image.data(), image_bytes, hipMemcpyHostToDevice));
+        ent->version = s.version;
+    }
+
+    // ---- kernel parameters
+    RenderParams P = cache.layout;
+    rt_camera cam;
+    derive_camera(s, &cam);
+    for (int i = 0; i < 3; ++i) {
+        P.cam.origin[i] = cam.origin[i];
+        P.cam.lower_left[i] = cam.lower_left[i];
+        P.cam.horizontal[i] = cam.horizontal[i];
+        P.cam.vertical[i] = cam.vertical[i];
+        P.cam.u[i] = cam.u[i];
+        P.cam.v[i] = cam.v[i];
+        P.background[i] = s.background[i];
+    }
+    P.cam.lens_radius = cam.lens_radius;
+    P.flags = s.flags;
+    P.width = s.width, P.height = s.height, P.max_depth = s.max_depth;
+    P.tile_rows = sh.tile_rows, P.tile_first = sh.tile_first, P.tile_stride = sh.tile_stride;
+    P.num_tiles = sh.num_tiles, P.local_rows = sh.local_rows;
+    P.sample_first = sample_first, P.sample_count = sample_count;
+    P.spp_chunk = spp_chunk, P.num_chunks = num_chunks;
+    uint64_t seed = o ? o->seed : 0;
+    P.seed_lo = (uint32_t)seed, P.seed_hi = (uint32_t)(seed >> 32);
+    P.blocks_x = (s.width + 31) / 32;
+    P.bands = (sh.local_rows + 7) / 8;
+
+    const size_t lds_bytes = (size_t)P.hot_vec4 * 16 + 4 * 192 * sizeof(float);
+    if (lds_bytes > 160 * 1024) {
+        set_error("scene needs %zu bytes of LDS per workgroup (limit 163840): too many primitives for the "
+                  "LDS-resident list",
+                  lds_bytes);
+        return RT_ERR_LIMIT;
+    }
+    if (lds_bytes > 64 * 1024 && set_max_dynamic_lds(lds_bytes)) {
+        set_error("cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
+        return RT_ERR_HIP;
+    }
+    const size_t plane = (size_t)sh.local_rows * s.width * 3;
+    const unsigned long long grid64 = (unsigned long long)P.blocks_x * P.bands * num_chunks;
+    if (grid64 > 0x7fffffffull) {
+        set_error("launch of %llu workgroups exceeds the grid limit", grid64);
+        return RT_ERR_LIMIT;
+    }
+
+    float *d_out = (float *)d_rgb_sum;
+    DevCounters *d_cnt = nullptr;
+    if (count) {
+        if (!ent->d_counters) HIP_TRY(hipMalloc((void **)&ent->d_counters, sizeof(DevCounters)));
+        d_cnt = ent->d_counters;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(DevCounters), stream));
+    }
+    if (stats) HIP_TRY(hipEventRecord(ev1, stream));
+
+    int launches = 0;
+    if (s.max_depth <= 0) {
+        // while (depth > 0) never runs: every sample is black (main.cpp:20,42)
+        HIP_TRY(hipMemsetAsync(d_out, 0, plane * sizeof(float), stream));
+    } else if (num_chunks == 1) {
+        launch_render(P, ent->d_image, d_out, d_cnt, lds_bytes, (unsigned)grid64, stream);
+        launches = 1;
+    } else {
+        size_t need = plane * num_chunks * sizeof(float);
+        if (ent->partial_bytes < need) {
+            if (ent->d_partial) HIP_TRY(hipFree(ent->d_partial));
+            ent->d_partial = nullptr;
+            ent->partial_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&ent->d_partial, need));
+            ent->partial_bytes = need;
+        }
+        launch_render(P, ent->d_image, ent->d_partial, d_cnt, lds_bytes, (unsigned)grid64, stream);
+        launch_reduce(ent->d_partial, d_out, plane, num_chunks, stream);
+        launches = 2;
+    }
+    HIP_TRY(hipGetLastError());
+
+    if (stats) {
+        HIP_TRY(hipEventRecord(ev2, stream));
+        HIP_TRY(hipEventSynchronize(ev2));
+        float up = 0, k = 0;
+        HIP_TRY(hipEventElapsedTime(&up, ev0, ev1));
+        HIP_TRY(hipEventElapsedTime(&k, ev1, ev2));
+        stats->upload_ms = up;
+        stats->kernel_ms = k;
+        stats->launches = launches;
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        (void)hipEventDestroy(ev2);
+        if (count) {
+            DevCounters h;
+            HIP_TRY(hipMemcpy(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost));
+            stats->samples = h.samples;
+            stats->queries = h.queries;
+            stats->prim_tests = h.queries * (unsigned long long)s.prims.size();
+            stats->hits = h.hits;
+            stats->misses = h.misses;
+            for (int i = 0; i < 4; ++i) stats->scatter[i] = h.scatter[i];
+            stats->rng_draws = h.rng_draws;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_render_hip_device(const rt_scene *s, const rt_opts *o, void *d_rgb_sum, void *stream, rt_stats *stats) {
+    return render_impl(s, o, d_rgb_sum, stream, stats, false);
+}
+
+static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_sum, rt_stats *stats, bool count) {
+    if (!sc) {
+        set_error("null scene");
+        return RT_ERR_ARG;
+    }
+    if (count && !stats) {
+        set_error("rt_render_hip_count needs a stats pointer");
+        return RT_ERR_ARG;
+    }
+    if (!count && !rgb_sum) {
+        set_error("null output buffer");
+        return RT_ERR_ARG;
+    }
+    Shard sh;
+    int rc = shard_of(sc->s, o, sh);
+    if (rc) return rc;
+    int device = o ? o->device : 0;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) {
+        set_error("no HIP device visible: the render path has no CPU fallback");
+        return RT_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("device %d out of range (%d visible)", device, ndev);
+        return RT_ERR_ARG;
+    }
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    if (prev != device) HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)sh.local_rows * sc->s.width * 3 * sizeof(float);
+    float *d_out = nullptr;
+    rt_stats local;
+    if (bytes) HIP_TRY(hipMalloc((void **)&d_out, bytes));
+    rc = bytes ? render_impl(sc, o, d_out, nullptr, stats ? stats : &local, count) : RT_OK;
+    if (rc == RT_OK && rgb_sum && bytes) {
+        hipError_t e = hipMemcpy(rgb_sum, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e));
+            rc = RT_ERR_HIP;
+        }
+    }
+    if (d_out) (void)hipFree(d_out);
+    if (prev != device) (void)hipSetDevice(prev);
+    return rc;
+}
+
+int rt_render_hip(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats *stats) {
+    return render_host_buffer(s, o, rgb_sum, stats, false);
+}
+
+int rt_render_hip_count(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats *stats) {
+    return render_host_buffer(s, o, rgb_sum, stats, true);
+}
+
+}  // extern "C"

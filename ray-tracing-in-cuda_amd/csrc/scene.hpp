@@ -1,0 +1,69 @@
+// Host scene model: the reference's object graph (gpu-version/parser.hpp:16-32
+// `struct scene` + the hittable/material/mytexture class hierarchy) flattened to
+// POD tables that one hipMemcpy can upload.  The reference instead re-`new`s every
+// object on the device from a <<<1,1>>> kernel to get device vtables
+// (gpu-version/main.cu:374-446); there are no virtual calls here, so that step is
+// designed away.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rtmi.h"
+
+namespace rtmi {
+
+struct CameraParams {
+    double lookfrom[3] = {0, 0, 1}, lookat[3] = {0, 0, 0}, vup[3] = {0, 1, 0};
+    double vfov = 40.0;
+    double aspect = 0.0;      // <= 0: width / height
+    double aperture = 0.0;
+    double focus_dist = 0.0;  // <= 0: |lookfrom - lookat|
+};
+
+// how a cylinder's transform was specified (kept for JSON serialisation)
+struct CylinderXform {
+    bool has_rotate = false, has_translate = false;
+    double axis[3] = {0, 0, 1};
+    double degrees = 0.0;
+    double offset[3] = {0, 0, 0};
+};
+
+struct DeviceSceneCache;  // owned by the render module
+
+struct Scene {
+    int width = 400, height = 225, spp = 100, max_depth = 50;
+    float background[3] = {0, 0, 0};
+    uint32_t flags = 0;
+    std::string output_file = "main.png";  // parser.hpp:566-567 default
+    CameraParams cam;
+    std::vector<rt_prim> prims;
+    std::vector<CylinderXform> xforms;  // parallel to prims (meaningful for cylinders)
+    std::vector<rt_material> mats;
+    std::vector<rt_texture> texs;
+    uint64_t version = 1;  // bumped on every mutation; invalidates device caches
+    std::shared_ptr<DeviceSceneCache> dev;
+
+    void touch() { ++version; }
+};
+
+// derive the camera frame (camera.cuh:9-29) in fp64, round once to fp32
+void derive_camera(const Scene &s, rt_camera *out);
+
+// all return RT_OK or an rt_status, message via set_error()
+int scene_from_json(const char *text, size_t len, Scene &out);
+std::string scene_to_json(const Scene &s);
+void scene_rtiow(Scene &out, uint32_t seed, int width, int height, int spp, int max_depth);
+int scene_validate(const Scene &s);
+
+int add_cylinder(Scene &s, float radius, float zmin, float zmax, int material, const double *axis,
+                 double degrees, const double *offset);
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *get_error();
+
+}  // namespace rtmi
+
+struct rt_scene {
+    rtmi::Scene s;
+};
