@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports every symbol include/rtmi.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+
+def _declared_functions(header_text):
+    text = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(rtmi):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = _declared_functions(open(os.path.join(root, "include", "rtmi.h")).read())
+    assert len(names) >= 35, names
+    lib = ctypes.CDLL(rtmi.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in rtmi.h but not exported: {missing}"
+    # the binding's own list must cover the header too
+    assert set(names) == set(rtmi.C_SYMBOLS)
+
+
+def test_abi_version_and_errors(rtmi):
+    assert rtmi.abi_version() == 1
+    lib = ctypes.CDLL(rtmi.LIB_PATH)
+    lib.rt_status_string.restype = ctypes.c_char_p
+    assert lib.rt_status_string(0) == b"ok"
+    assert b"JSON" in lib.rt_status_string(3)
+
+
+def test_struct_layouts_match_checker(rtmi):
+    # tests hand the product's tables to the checker verbatim
+    assert rtmi.PRIM_DTYPE.itemsize == 128
+    assert rtmi.MATERIAL_DTYPE.itemsize == 28
+    assert rtmi.TEXTURE_DTYPE.itemsize == 28
+    assert ctypes.sizeof(rtmi.Opts) == 40
+    assert ctypes.sizeof(rtmi.Stats) == 8 * 2 + 4 * 2 + 8 * 5 + 8 * 4 + 8
+
+
+def test_no_oracle_in_product():
+    """The shipped library must not reference the CPU checkers in any way."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "ray-tracing-in-cuda_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".hpp", ".py")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "rt_oracle" not in text and "librt_oracle" not in text and "libref_cpu" not in text, f
+                assert "rto_" not in text, f
