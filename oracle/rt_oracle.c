@@ -544,12 +544,25 @@ static void counts_add(rto_counts *a, const rto_counts *b) {
     a->rng_draws += b->rng_draws;
 }
 
+/* Pixel accumulation.  The reference adds sample radiances into a running sum
+ * (res += ray_color(...), cpu/main.cpp:47,52: fp64; gpu/main.cu:100: fp32).  Here each
+ * fp32 sample is converted to 64-bit fixed point with 32 fractional bits (round to nearest
+ * even) and summed in integers: exact, hence independent of the order in which samples
+ * finish -- which lets the HIP kernel hand samples of a tile to whichever lane is free.
+ * (resolution 2^-32 per sample, closer to the fp64 reference than an fp32 running sum). */
+static uint64_t radiance_to_fixed(float v) {
+    if (!(fabsf(v) <= 1e9f)) v = (v != v) ? 0.0f : copysignf(1e9f, v); /* NaN -> 0, clamp */
+    return (uint64_t)llrint((double)v * 4294967296.0);
+}
+static float fixed_to_sum(uint64_t t) { return (float)((double)(int64_t)t * (1.0 / 4294967296.0)); }
+
 /* render() per pixel, cpu/main.cpp:45-55, over the pixel loop of :99-106.
- * Samples are summed in sample order inside a chunk, chunk sums in chunk order. */
+ * spp_chunk is accepted for interface symmetry with rt_opts and has no effect on the
+ * result (the sum is exact). */
 int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_first,
                int sample_count, int spp_chunk, float *rgb_sum, rto_counts *counts, int threads) {
+    (void)spp_chunk;
     if (!s || !rgb_sum || y0 < 0 || y1 > s->height || y0 > y1 || sample_count < 0) return 1;
-    if (spp_chunk <= 0) spp_chunk = sample_count > 0 ? sample_count : 1;
     rto_counts total;
     memset(&total, 0, sizeof total);
 #ifdef _OPENMP
@@ -564,19 +577,16 @@ int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_fir
 #pragma omp for schedule(dynamic, 1)
         for (int y = y0; y < y1; ++y) {
             for (int x = 0; x < s->width; ++x) {
-                float tot[3] = {0.0f, 0.0f, 0.0f};
-                for (int c0 = 0; c0 < sample_count; c0 += spp_chunk) {
-                    int c1 = c0 + spp_chunk < sample_count ? c0 + spp_chunk : sample_count;
-                    float cs[3] = {0.0f, 0.0f, 0.0f};
-                    for (int k = c0; k < c1; ++k) {
-                        float rgb[3];
-                        rto_sample(s, seed, x, y, sample_first + k, rgb, counts ? &local : 0);
-                        cs[0] += rgb[0], cs[1] += rgb[1], cs[2] += rgb[2];
-                    }
-                    tot[0] += cs[0], tot[1] += cs[1], tot[2] += cs[2];
+                uint64_t tot[3] = {0, 0, 0};
+                for (int k = 0; k < sample_count; ++k) {
+                    float rgb[3];
+                    rto_sample(s, seed, x, y, sample_first + k, rgb, counts ? &local : 0);
+                    tot[0] += radiance_to_fixed(rgb[0]);
+                    tot[1] += radiance_to_fixed(rgb[1]);
+                    tot[2] += radiance_to_fixed(rgb[2]);
                 }
                 float *o = rgb_sum + ((size_t)y * s->width + x) * 3;
-                o[0] = tot[0], o[1] = tot[1], o[2] = tot[2];
+                o[0] = fixed_to_sum(tot[0]), o[1] = fixed_to_sum(tot[1]), o[2] = fixed_to_sum(tot[2]);
             }
         }
 #pragma omp critical

@@ -7,6 +7,7 @@
 // state to allocate or initialise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -17,9 +18,9 @@
 
 namespace rtmi {
 
-void launch_render(const RenderParams &P, const void *image, float *out, DevCounters *counters, size_t lds_bytes,
-                   unsigned grid, hipStream_t stream);
-void launch_reduce(const float *partial, float *out, size_t plane, int num_chunks, hipStream_t stream);
+void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, DevCounters *counters,
+                   size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant);
+void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream);
 int set_max_dynamic_lds(size_t bytes);
 
 #define HIP_TRY(expr)                                                                         \
@@ -36,8 +37,8 @@ struct DeviceEntry {
     uint64_t version = 0;
     void *d_image = nullptr;
     size_t image_bytes = 0;
-    float *d_partial = nullptr;
-    size_t partial_bytes = 0;
+    unsigned long long *d_acc = nullptr;  // fixed-point pixel accumulators of the last launch
+    size_t acc_bytes = 0;
     DevCounters *d_counters = nullptr;
 };
 
@@ -55,7 +56,7 @@ struct DeviceSceneCache {
             if (e.device < 0) continue;
             if (hipSetDevice(e.device) != hipSuccess) continue;
             if (e.d_image) (void)hipFree(e.d_image);
-            if (e.d_partial) (void)hipFree(e.d_partial);
+            if (e.d_acc) (void)hipFree(e.d_acc);
             if (e.d_counters) (void)hipFree(e.d_counters);
         }
         if (have) (void)hipSetDevice(cur);
@@ -78,11 +79,17 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         default: rec.push_back((int)i); break;
         }
     }
+    // big spheres first: they are the likeliest closest hits, which makes the kernel's
+    // "farther than the current best" reject effective early (order does not change results)
+    std::stable_sort(sph.begin(), sph.end(), [&](int a, int b) {
+        return std::fabs(s.prims[a].f[3]) > std::fabs(s.prims[b].f[3]);
+    });
     RenderParams &L = c.layout;
     memset(&L, 0, sizeof L);
     L.ns = (int)sph.size(), L.nr = (int)rec.size(), L.nc = (int)cyl.size(), L.nm = (int)s.mats.size();
+    L.ns_pad = (L.ns + 3) / 4 * 4;
     int off = 0;
-    off += L.ns;  // sphere hot
+    off += L.ns_pad + 4;  // sphere hot (+ never-hit padding)
     L.off_rect_hot = off;
     off += 2 * L.nr;
     L.off_cyl_hot = off;
@@ -100,6 +107,7 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     float *I = c.image.data();
     auto rec4 = [&](int idx) { return I + (size_t)idx * 4; };
 
+    for (int k = L.ns; k < L.ns_pad + 4; ++k) rec4(k)[3] = -INFINITY;  // c = +inf, disc = -inf: never a candidate
     for (int k = 0; k < L.ns; ++k) {
         const rt_prim &p = s.prims[sph[k]];
         float *h = rec4(k);
@@ -276,6 +284,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         return RT_ERR_ARG;
     }
 
+    const unsigned variant = o ? o->variant : 0;
+    if (variant > 3) {
+        set_error("unknown kernel variant %u", variant);
+        return RT_ERR_ARG;
+    }
     int device = o ? o->device : 0;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -358,7 +371,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     P.blocks_x = (s.width + 31) / 32;
     P.bands = (sh.local_rows + 7) / 8;
 
-    const size_t lds_bytes = (size_t)P.hot_vec4 * 16 + 4 * 192 * sizeof(float);
+    const size_t lds_bytes = (size_t)P.hot_vec4 * 16 + 4 * 192 * sizeof(unsigned long long);
     if (lds_bytes > 160 * 1024) {
         set_error("scene needs %zu bytes of LDS per workgroup (limit 163840): too many primitives for the "
                   "LDS-resident list",
@@ -389,20 +402,18 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     if (s.max_depth <= 0) {
         // while (depth > 0) never runs: every sample is black (main.cpp:20,42)
         HIP_TRY(hipMemsetAsync(d_out, 0, plane * sizeof(float), stream));
-    } else if (num_chunks == 1) {
-        launch_render(P, ent->d_image, d_out, d_cnt, lds_bytes, (unsigned)grid64, stream);
-        launches = 1;
     } else {
-        size_t need = plane * num_chunks * sizeof(float);
-        if (ent->partial_bytes < need) {
-            if (ent->d_partial) HIP_TRY(hipFree(ent->d_partial));
-            ent->d_partial = nullptr;
-            ent->partial_bytes = 0;
-            HIP_TRY(hipMalloc((void **)&ent->d_partial, need));
-            ent->partial_bytes = need;
+        const size_t need = plane * sizeof(unsigned long long);
+        if (ent->acc_bytes < need) {
+            if (ent->d_acc) HIP_TRY(hipFree(ent->d_acc));
+            ent->d_acc = nullptr;
+            ent->acc_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&ent->d_acc, need));
+            ent->acc_bytes = need;
         }
-        launch_render(P, ent->d_image, ent->d_partial, d_cnt, lds_bytes, (unsigned)grid64, stream);
-        launch_reduce(ent->d_partial, d_out, plane, num_chunks, stream);
+        HIP_TRY(hipMemsetAsync(ent->d_acc, 0, need, stream));
+        launch_render(P, ent->d_image, ent->d_acc, d_cnt, lds_bytes, (unsigned)grid64, stream, variant);
+        launch_finalize(ent->d_acc, d_out, plane, stream);
         launches = 2;
     }
     HIP_TRY(hipGetLastError());

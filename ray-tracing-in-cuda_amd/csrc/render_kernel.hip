@@ -1,5 +1,4 @@
-// The hot path: one work-item owns one pixel (of one sample chunk) and runs the whole
-// sample-and-bounce loop.  gfx950 (MI355X) only.
+// The hot path: per-pixel path tracing on gfx950 (MI355X).
 //
 // Replaces   render<<<(W/8+1,H/8+1),(8,8)>>>   gpu-version/main.cu:72-105
 //            ray_color                         gpu-version/main.cu:17-70  (semantics:
@@ -10,18 +9,26 @@
 //            curand XORWOW per-pixel state     -> stateless Philox4x32-10 (philox.h)
 //
 // Shape of the kernel
-//   * 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel tile (coherent
-//     primary rays), the workgroup a 32x8 strip of one row tile.
+//   * 256-thread workgroup = 4 wave64.  A wave owns an 8x8 pixel tile and a range of
+//     sample indices; a work-item (lane) owns ONE PATH at a time and runs its whole
+//     bounce loop (get_color), exactly as the reference's thread does for its pixel.
+//   * lanes stay converged across bounces: every iteration of the main loop is one
+//     closest-hit query for all live lanes over a wave-uniform primitive loop.  A lane
+//     whose path ended adds the radiance to its pixel and immediately takes the next
+//     (pixel, sample) item of the tile's pool -- __ballot of the idle lanes, mbcnt for
+//     the rank, a wave-uniform cursor -- so no lane waits for the slowest pixel of the
+//     tile; the loop leaves on !__any(active) with the pool empty.
+//     (variant bit 0 restores strict ownership: a lane only takes samples of its own
+//     pixel.  Results are identical; it is kept to measure what the pool buys.)
+//   * that hand-off is legal because the per-pixel sum is exact: each fp32 sample is
+//     added as 64-bit fixed point (2^-32), in LDS per tile, then one 64-bit global
+//     atomic per pixel and channel; a second kernel converts to the fp32 framebuffer
+//     with fully coalesced stores.
 //   * the primitive tables the inner loop reads ("hot" part of the scene image,
-//     device_scene.h) are copied into LDS once per workgroup; all lanes of a wave
-//     read the same record each iteration, i.e. one broadcast ds_read_b128 per
-//     sphere.  No virtual calls, no pointer chasing; cold data (1/r, material
-//     records) stays in global memory and is read once per bounce.
-//   * lanes stay converged across bounces: the loop body is one closest-hit query
-//     for every live lane; a lane whose path ends (miss / absorbed / depth) adds the
-//     radiance to its pixel sum and starts its NEXT sample in the same iteration, so
-//     the wave-uniform primitive loop always runs with full occupancy; the loop
-//     leaves on !__any(active).
+//     device_scene.h) are copied into LDS once per workgroup; all lanes read the same
+//     record (broadcast ds_read_b128), four spheres are fetched one batch ahead of use.
+//     No virtual calls, no pointer chasing; cold data (1/r, material records) stays in
+//     global memory / L2 and is read once per bounce.
 //   * arithmetic: fp32, every fused multiply-add explicit (-ffp-contract=off), IEEE
 //     sqrt and divide, so results are bit-identical to the scalar restatement the
 //     tests check against.
@@ -92,15 +99,29 @@ __device__ __forceinline__ int list_index_of(const RenderParams &P, const float4
     return __float_as_int(image[P.off_cyl_cold + 4 * (id - P.ns - P.nr) + 3].y);
 }
 
+// radiance sample -> 64-bit fixed point with 32 fractional bits, round to nearest even;
+// NaN -> 0, magnitude clamped to 1e9 (a pixel sum is exact while it stays below 2^31)
+__device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
+    if (!(fabsf(v) <= 1e9f)) v = (v != v) ? 0.0f : copysignf(1e9f, v);
+    return (unsigned long long)__double2ll_rn((double)v * 4294967296.0);
+}
+
 // ---------------------------------------------------------------- kernel
-template <bool COUNT>
+// POOL:     idle lanes take the next (pixel, sample) item of the wave's tile (default)
+//           / false: a lane only renders samples of its own pixel
+// PREFETCH: sphere records are read from LDS one batch of four ahead (default)
+//           / false: one record per iteration, waited for in place
+template <bool COUNT, bool POOL, bool PREFETCH>
 __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
-                                                     float *__restrict__ out, DevCounters *__restrict__ counters) {
+                                                     unsigned long long *__restrict__ acc,
+                                                     DevCounters *__restrict__ counters) {
     extern __shared__ float4 lds[];
     // stage the hot tables (hittable_list contents) into LDS
     for (int i = threadIdx.x; i < P.hot_vec4; i += 256) lds[i] = image[i];
+    // per-wave tile accumulators: 64 pixels x rgb, 64-bit fixed point
+    unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + P.hot_vec4);
+    for (int i = threadIdx.x; i < 4 * 64 * 3; i += 256) tile_acc[i] = 0ull;
     __syncthreads();
-    float *stage = reinterpret_cast<float *>(lds + P.hot_vec4);  // 4 waves x 192 floats
 
     // workgroup -> (sample chunk, 8-row band of the shard, 32-pixel strip)
     int b = blockIdx.x;
@@ -109,11 +130,14 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
     const int band = b % P.bands;
     const int chunk = b / P.bands;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x = bx * 32 + wave * 8 + (lane & 7);
-    const int lr = band * 8 + (lane >> 3);  // dense local row of this shard
-    const int tl = lr / P.tile_rows;
-    const int y = (P.tile_first + tl * P.tile_stride) * P.tile_rows + (lr - tl * P.tile_rows);
-    const bool valid = x < P.width && lr < P.local_rows && y < P.height;
+    const int x0 = bx * 32 + wave * 8;
+    // this lane's home pixel (the one it flushes at the end; with !POOL the one it renders)
+    const int hx = x0 + (lane & 7);
+    const int hlr = band * 8 + (lane >> 3);  // dense local row of this shard
+    const int htl = hlr / P.tile_rows;
+    const int hy = (P.tile_first + htl * P.tile_stride) * P.tile_rows + (hlr - htl * P.tile_rows);
+    const int hvalid = (hx < P.width && hlr < P.local_rows && hy < P.height) ? 1 : 0;
+    unsigned long long *my_acc = tile_acc + wave * 192;
 
     const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
     const float4 *sph = lds;
@@ -121,66 +145,94 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
     const float4 *cyl = lds + P.off_cyl_hot;
     const int ns = P.ns, nr = P.nr, nc = P.nc;
 
-    int s_next = P.sample_first + chunk * P.spp_chunk;
-    int s_end = s_next + P.spp_chunk;
-    if (s_end > P.sample_first + P.sample_count) s_end = P.sample_first + P.sample_count;
-    if (!valid) s_end = s_next;
+    const int s_begin = P.sample_first + chunk * P.spp_chunk;
+    int s_stop = s_begin + P.spp_chunk;
+    if (s_stop > P.sample_first + P.sample_count) s_stop = P.sample_first + P.sample_count;
+    const int n_samples = s_stop - s_begin;  // wave-uniform
+    const int pool_items = n_samples * 64;   // item k = (pixel k & 63, sample s_begin + (k >> 6))
+    int cursor = 0;                          // POOL: wave-uniform pool cursor
+    int mine = 0;                            // !POOL: samples of the home pixel started so far
 
-    const float fx = (float)x, fy = (float)y;
     const float wm1 = (float)(P.width - 1), hm1 = (float)(P.height - 1);
-    const uint32_t pixel_id = (uint32_t)(y * P.width + x);
 
     LaneRng rng;
-    rng.pixel = pixel_id, rng.sample = 0, rng.block = 0, rng.pos = 4, rng.draws = 0;
+    rng.pixel = 0, rng.sample = 0, rng.block = 0, rng.pos = 4, rng.draws = 0;
     rng.b0 = rng.b1 = rng.b2 = rng.b3 = 0;
 
-    float sum_r = 0.0f, sum_g = 0.0f, sum_b = 0.0f;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, ra = 1, rinv_a = 1;
     float beta_r = 1, beta_g = 1, beta_b = 1, L_r = 0, L_g = 0, L_b = 0;
     int depth = 0;
+    int cur_p = lane;  // tile-local pixel of the path this lane is tracing
     bool active = false;
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
     uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0;
 
     for (;;) {
-        // ---- refill: a lane without a live path starts its next sample
+        // ---- refill: lanes without a live path take new samples
         // (render()'s sample loop, main.cu:95-101; camera::get_ray camera.h:32-39)
-        if (!active && s_next < s_end) {
-            rng_start(rng, pixel_id, (uint32_t)s_next);
-            s_next++;
-            float u = (fx + rng_next<COUNT>(rng, k0, k1)) / wm1;
-            float v = (fy + rng_next<COUNT>(rng, k0, k1)) / hm1;
-            float offx = 0.0f, offy = 0.0f, offz = 0.0f;
-            if (P.flags & RT_FLAG_DEFOCUS_BLUR) {
-                float px, py;
-                do {  // random_in_unit_disk, vec3.h:157-165
-                    px = rng_pm1<COUNT>(rng, k0, k1);
-                    py = rng_pm1<COUNT>(rng, k0, k1);
-                } while (fmaf(px, px, py * py) >= 1.0f);
-                float rdx = P.cam.lens_radius * px, rdy = P.cam.lens_radius * py;
-                offx = fmaf(P.cam.u[0], rdx, P.cam.v[0] * rdy);
-                offy = fmaf(P.cam.u[1], rdx, P.cam.v[1] * rdy);
-                offz = fmaf(P.cam.u[2], rdx, P.cam.v[2] * rdy);
+        const bool need = !active;
+        const unsigned long long idle = __ballot(need);
+        if (idle) {  // wave-uniform
+            bool start = false;
+            int sp = 0, spx = 0, spy = 0, ss = 0;
+            if (POOL) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const int k = cursor + rank;
+                cursor = min(cursor + (int)__popcll(idle), pool_items);
+                sp = k & 63;
+                // row and validity of pixel sp live in lane sp's registers (all lanes take part)
+                spy = __shfl(hy, sp, 64);
+                const int pv = __shfl(hvalid, sp, 64);
+                spx = x0 + (sp & 7);
+                ss = s_begin + (k >> 6);
+                start = need && k < pool_items && pv != 0;
+            } else {
+                start = need && mine < n_samples && hvalid != 0;
+                sp = lane, spx = hx, spy = hy, ss = s_begin + mine;
+                if (start) mine++;
             }
-            dx = fmaf(v, P.cam.vertical[0], fmaf(u, P.cam.horizontal[0], P.cam.lower_left[0]));
-            dy = fmaf(v, P.cam.vertical[1], fmaf(u, P.cam.horizontal[1], P.cam.lower_left[1]));
-            dz = fmaf(v, P.cam.vertical[2], fmaf(u, P.cam.horizontal[2], P.cam.lower_left[2]));
-            dx = (dx - P.cam.origin[0]) - offx;
-            dy = (dy - P.cam.origin[1]) - offy;
-            dz = (dz - P.cam.origin[2]) - offz;
-            ox = P.cam.origin[0] + offx;
-            oy = P.cam.origin[1] + offy;
-            oz = P.cam.origin[2] + offz;
-            ra = dot3(dx, dy, dz, dx, dy, dz);
-            rinv_a = 1.0f / ra;
-            beta_r = beta_g = beta_b = 1.0f;
-            L_r = L_g = L_b = 0.0f;
-            depth = P.max_depth;
-            active = true;
-            if (COUNT) c_samples++;
+            if (start) {
+                cur_p = sp;
+                rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss);
+                float u = ((float)spx + rng_next<COUNT>(rng, k0, k1)) / wm1;
+                float v = ((float)spy + rng_next<COUNT>(rng, k0, k1)) / hm1;
+                float offx = 0.0f, offy = 0.0f, offz = 0.0f;
+                if (P.flags & RT_FLAG_DEFOCUS_BLUR) {
+                    float px, py;
+                    do {  // random_in_unit_disk, vec3.h:157-165
+                        px = rng_pm1<COUNT>(rng, k0, k1);
+                        py = rng_pm1<COUNT>(rng, k0, k1);
+                    } while (fmaf(px, px, py * py) >= 1.0f);
+                    float rdx = P.cam.lens_radius * px, rdy = P.cam.lens_radius * py;
+                    offx = fmaf(P.cam.u[0], rdx, P.cam.v[0] * rdy);
+                    offy = fmaf(P.cam.u[1], rdx, P.cam.v[1] * rdy);
+                    offz = fmaf(P.cam.u[2], rdx, P.cam.v[2] * rdy);
+                }
+                dx = fmaf(v, P.cam.vertical[0], fmaf(u, P.cam.horizontal[0], P.cam.lower_left[0]));
+                dy = fmaf(v, P.cam.vertical[1], fmaf(u, P.cam.horizontal[1], P.cam.lower_left[1]));
+                dz = fmaf(v, P.cam.vertical[2], fmaf(u, P.cam.horizontal[2], P.cam.lower_left[2]));
+                dx = (dx - P.cam.origin[0]) - offx;
+                dy = (dy - P.cam.origin[1]) - offy;
+                dz = (dz - P.cam.origin[2]) - offz;
+                ox = P.cam.origin[0] + offx;
+                oy = P.cam.origin[1] + offy;
+                oz = P.cam.origin[2] + offz;
+                ra = dot3(dx, dy, dz, dx, dy, dz);
+                rinv_a = 1.0f / ra;
+                beta_r = beta_g = beta_b = 1.0f;
+                L_r = L_g = L_b = 0.0f;
+                depth = P.max_depth;
+                active = true;
+                if (COUNT) c_samples++;
+            }
         }
-        if (!__any(active)) break;  // every lane of the wave is out of samples
+        if (!__any(active)) {
+            // no lane found work: done, unless the pool only handed out off-image pixels so far
+            if (!POOL || cursor >= pool_items) break;
+            continue;
+        }
 
         if (active) {
             // ---- closest-hit query over the LDS-resident list (hittable_list::hit,
@@ -192,23 +244,51 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
             //   disc < 0                      -> no real root
             //   hb >= 0 and c >= 0            -> both roots <= 0 < t_min  (then
             //     sqrt(disc) <= sqrt(fl(hb*hb)) = hb, so (-hb + sqrtd) <= 0 exactly)
-#pragma unroll 4
-            for (int i = 0; i < ns; ++i) {
-                const float4 s = sph[i];
-                const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
-                const float hb = dot3(ocx, ocy, ocz, dx, dy, dz);
-                const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -s.w)));
-                const float disc = fmaf(hb, hb, -(ra * cc));
-                if (!(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f)) {
-                    const float sq = sqrtf(disc);
-                    float root = (-hb - sq) * rinv_a;
-                    if (root < kTMin || best_t < root) root = (-hb + sq) * rinv_a;
-                    if (!(root < kTMin || best_t < root)) {
+            // The closest hit does not depend on the visiting order (ties go to the later
+            // list entry, resolved through list_index_of), so the device table is sorted
+            // big-spheres-first.
+            auto resolve = [&](int idx, float hb, float disc) {
+                const float sq = sqrtf(disc);
+                float root = (-hb - sq) * rinv_a;
+                if (root < kTMin || best_t < root) root = (-hb + sq) * rinv_a;
+                if (!(root < kTMin || best_t < root)) {
+                    bool take = true;
+                    if (root == best_t && best_id >= 0)
+                        take = list_index_of(P, image, idx) > list_index_of(P, image, best_id);
+                    if (take) {
                         best_t = root;
-                        best_id = i;
+                        best_id = idx;
                     }
                 }
+            };
+#define RT_SPHERE_TEST(S, IDX)                                                                 \
+    {                                                                                          \
+        const float ocx = ox - S.x, ocy = oy - S.y, ocz = oz - S.z;                            \
+        const float hb = dot3(ocx, ocy, ocz, dx, dy, dz);                                      \
+        const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -S.w)));                 \
+        const float disc = fmaf(hb, hb, -(ra * cc));                                           \
+        if (!(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f)) resolve(IDX, hb, disc);            \
+    }
+            if (PREFETCH) {
+                // the table is padded to a multiple of 4 with never-hit records (r*r = -inf)
+                // plus 4 more, so fetching the next batch never leaves the table
+                float4 n0 = sph[0], n1 = sph[1], n2 = sph[2], n3 = sph[3];
+                for (int i = 0; i < P.ns_pad; i += 4) {
+                    const float4 s0 = n0, s1 = n1, s2 = n2, s3 = n3;
+                    n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7];
+                    RT_SPHERE_TEST(s0, i)
+                    RT_SPHERE_TEST(s1, i + 1)
+                    RT_SPHERE_TEST(s2, i + 2)
+                    RT_SPHERE_TEST(s3, i + 3)
+                }
+            } else {
+#pragma unroll 4
+                for (int i = 0; i < ns; ++i) {
+                    const float4 s = sph[i];
+                    RT_SPHERE_TEST(s, i)
+                }
             }
+#undef RT_SPHERE_TEST
 
             // axis-aligned rects: xy_rect/xz_rect/yz_rect::hit, object.cuh:105-192
             for (int j = 0; j < nr; ++j) {
@@ -440,33 +520,25 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
                 path_done = true;
                 if (COUNT) c_misses++;
             }
-            if (path_done) {  // res += ray_color(...), main.cu:100
-                sum_r += L_r, sum_g += L_g, sum_b += L_b;
+            if (path_done) {  // res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
+                unsigned long long *a = my_acc + cur_p * 3;
+                atomicAdd(a + 0, radiance_to_fixed(L_r));
+                atomicAdd(a + 1, radiance_to_fixed(L_g));
+                atomicAdd(a + 2, radiance_to_fixed(L_b));
                 active = false;
             }
         }
     }
 
-    // ---- coalesced framebuffer store: transpose the wave's 8x8x3 tile through LDS so
-    // each store instruction writes the 96-byte row segments contiguously
-    // (image[y*W + x] = res, main.cu:104; layout rgb_sum[(row*W + x)*3 + c])
-    float *st = stage + wave * 192;
-    st[lane * 3 + 0] = sum_r;
-    st[lane * 3 + 1] = sum_g;
-    st[lane * 3 + 2] = sum_b;
+    // ---- tile -> global accumulators (image[y*W + x] += res; one 64-bit atomic per channel:
+    // other sample chunks of the same pixels run in other workgroups)
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes landed (wave-private region)
-    const int x0 = bx * 32 + wave * 8;
-    const int lr0 = band * 8;
-    const size_t plane = (size_t)P.local_rows * P.width * 3;
-    float *dst = out + (size_t)chunk * plane;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int f = lane + 64 * r;
-        const int row = f / 24, col = f - row * 24;
-        const int xx = x0 + col / 3;
-        const int rr = lr0 + row;
-        if (xx < P.width && rr < P.local_rows) dst[((size_t)rr * P.width + x0) * 3 + col] = st[f];
+    if (hvalid) {
+        unsigned long long *g = acc + ((size_t)hlr * P.width + hx) * 3;
+        const unsigned long long *a = my_acc + lane * 3;
+        atomicAdd(g + 0, a[0]);
+        atomicAdd(g + 1, a[1]);
+        atomicAdd(g + 2, a[2]);
     }
 
     if (COUNT) {
@@ -488,38 +560,46 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
     }
 }
 
-// chunk partial sums -> pixel sums, in chunk order (0 + c0 + c1 + ...)
-__global__ __launch_bounds__(256) void reduce_chunks_kernel(const float *__restrict__ partial, float *__restrict__ out,
-                                                            size_t plane, int num_chunks) {
+// fixed-point pixel sums -> fp32 framebuffer (rgb_sum[(row*W + x)*3 + c]); every store
+// instruction writes 256 contiguous bytes
+__global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long *__restrict__ acc,
+                                                       float *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= plane) return;
-    float t = 0.0f;
-    for (int c = 0; c < num_chunks; ++c) t += partial[(size_t)c * plane + i];
-    out[i] = t;
+    if (i < n) out[i] = (float)((double)(long long)acc[i] * (1.0 / 4294967296.0));
 }
 
-// launchers used by render_hip.cpp (host code compiled by the host compiler pass)
-void launch_render(const RenderParams &P, const void *image, float *out, DevCounters *counters, size_t lds_bytes,
-                   unsigned grid, hipStream_t stream) {
-    if (counters)
-        hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(256), lds_bytes, stream, P,
-                           (const float4 *)image, out, counters);
-    else
-        hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(256), lds_bytes, stream, P,
-                           (const float4 *)image, out, (DevCounters *)nullptr);
+// launchers used by render_host.hip
+void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, DevCounters *counters,
+                   size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
+    const float4 *img = (const float4 *)image;
+    const dim3 g(grid), t(256);
+    if (counters) {
+        hipLaunchKernelGGL((render_kernel<true, true, true>), g, t, lds_bytes, stream, P, img, acc, counters);
+        return;
+    }
+    DevCounters *none = nullptr;
+    switch (variant & 3u) {
+    case 0: hipLaunchKernelGGL((render_kernel<false, true, true>), g, t, lds_bytes, stream, P, img, acc, none); break;
+    case 1: hipLaunchKernelGGL((render_kernel<false, false, true>), g, t, lds_bytes, stream, P, img, acc, none); break;
+    case 2: hipLaunchKernelGGL((render_kernel<false, true, false>), g, t, lds_bytes, stream, P, img, acc, none); break;
+    default: hipLaunchKernelGGL((render_kernel<false, false, false>), g, t, lds_bytes, stream, P, img, acc, none); break;
+    }
 }
 
-void launch_reduce(const float *partial, float *out, size_t plane, int num_chunks, hipStream_t stream) {
-    unsigned grid = (unsigned)((plane + 255) / 256);
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3(grid), dim3(256), 0, stream, partial, out, plane, num_chunks);
+void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream) {
+    unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(256), 0, stream, acc, out, n);
 }
 
 int set_max_dynamic_lds(size_t bytes) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 1;
+    const void *fns[5] = {reinterpret_cast<const void *>(&render_kernel<false, true, true>),
+                          reinterpret_cast<const void *>(&render_kernel<false, false, true>),
+                          reinterpret_cast<const void *>(&render_kernel<false, true, false>),
+                          reinterpret_cast<const void *>(&render_kernel<false, false, false>),
+                          reinterpret_cast<const void *>(&render_kernel<true, true, true>)};
+    for (const void *f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+    return 0;
 }
 
 }  // namespace rtmi

@@ -1,6 +1,7 @@
 """-m gpu: the HIP render path, called through the C ABI, against the CPU checker
 (oracle/rt_oracle.c) on the same seeded inputs.  The bar is BIT-EXACT fp32 framebuffers
 (stricter than north_star's 1e-3 per-pixel tolerance, which is also asserted explicitly),
+including the exact fixed-point pixel accumulation both sides define,
 plus the reference-produced golden vectors and size-independent properties at the
 BASELINE.json frame size."""
 import ctypes as C
@@ -108,18 +109,32 @@ def test_partition_invariance(rtmi, scenes_dir, golden_dir, world, tile_rows):
 
 
 def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
+    """The pixel sum is exact (64-bit fixed point), so how the samples are cut into
+    work-items (spp_chunk) cannot change a bit; sample ranges select Philox streams."""
     sc = _scene(rtmi, scenes_dir, golden_dir, "three_sphere")
     sc.override(width=40, height=24, spp=13)
+    whole = _assert_same(rtmi, rtcheck, sc)
     for chunk in (1, 4, 13, 64):
-        _assert_same(rtmi, rtcheck, sc, spp_chunk=chunk)
+        assert np.array_equal(whole, sc.render(rtmi.Opts(seed=SEED, spp_chunk=chunk)))
     # progressive accumulation: samples [5, 13) alone
     _assert_same(rtmi, rtcheck, sc, sample_first=5, sample_count=8)
-    # chunk sums are the sums of the sample ranges: spp_chunk = 1 is the fp32 sum of 13 one-sample frames
-    per = [sc.render(rtmi.Opts(seed=SEED, sample_first=k, sample_count=1)) for k in range(13)]
-    acc = np.zeros_like(per[0])
-    for p in per:
-        acc = acc + p
-    assert np.array_equal(acc, sc.render(rtmi.Opts(seed=SEED, spp_chunk=1)))
+    # the frame is the sum of its one-sample frames (up to the single final rounding to fp32)
+    per = [sc.render(rtmi.Opts(seed=SEED, sample_first=k, sample_count=1)).astype(np.float64) for k in range(13)]
+    acc = np.sum(per, axis=0)
+    assert np.abs(acc - whole).max() <= 13 * 2.0 ** -24 * max(1.0, acc.max())
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir, variant):
+    """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
+    bit 1: unbatched sphere loop.  Same bits as the checker in every combination."""
+    for name, w, h, spp in (("rtiow", 72, 40, 6), ("mixed_emissive", 50, 30, 5)):
+        sc = _scene(rtmi, scenes_dir, golden_dir, name)
+        sc.override(width=w, height=h, spp=spp)
+        _assert_same(rtmi, rtcheck, sc, variant=variant)
+        _assert_same(rtmi, rtcheck, sc, variant=variant, spp_chunk=2)
+    with pytest.raises(rtmi.RtmiError, match="variant"):
+        sc.render(rtmi.Opts(variant=9))
 
 
 def test_exact_event_counters(rtmi, rtcheck, scenes_dir, golden_dir):
@@ -203,7 +218,7 @@ def test_device_pointer_and_stream_api(rtmi, scenes_dir, golden_dir):
     assert np.array_equal(buf.cpu().numpy(), want)
     st = rtmi.Stats()
     sc.render_device(rtmi.Opts(seed=SEED), buf.data_ptr(), 0, st)
-    assert st.kernel_ms > 0 and st.launches == 1 and st.local_rows == 40
+    assert st.kernel_ms > 0 and st.launches == 2 and st.local_rows == 40
 
 
 def test_error_behaviour(rtmi, scenes_dir, golden_dir):
