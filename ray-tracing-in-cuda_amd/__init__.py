@@ -26,7 +26,8 @@ except Exception:  # pragma: no cover - torch is optional for the binding itself
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "librtmi.so")
+# RTMI_LIB: alternative build of the same library (kernel tuning A/B); default is the in-tree one
+_LIB_PATH = os.environ.get("RTMI_LIB") or os.path.join(_HERE, "librtmi.so")
 if not os.path.exists(_LIB_PATH):
     raise ImportError(
         f"{_LIB_PATH} not found: build it with `make -C {_HERE}` (or __graft_entry__.build()); "

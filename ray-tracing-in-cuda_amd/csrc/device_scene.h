@@ -3,7 +3,7 @@
 //
 //   HOT part (copied into LDS by every workgroup; everything the primitive loop reads)
 //     sphere  [ns_pad + 4]  1 x float4   {cx, cy, cz, r*r}   sorted by |r| descending, padded with
-//                                never-hit records (r*r = -inf) to a multiple of 4, plus 4 more
+//                                never-hit records (r*r = -inf) to a multiple of 8, plus 4 more
 //     rect    [nr]  2 x float4   {a0, a1, b0, b1} {k, axis(bits), 0, 0}
 //     cyl     [nc]  4 x float4   m_inv rows 0..2, {radius^2, zmin, zmax, 0}
 //   COLD part (stays in global memory / L2; read once per bounce by the winning lane)
@@ -48,7 +48,7 @@ struct RenderParams {
     uint32_t seed_lo, seed_hi;
     // scene image
     int32_t ns, nr, nc, nm;
-    int32_t ns_pad;          // sphere records incl. never-hit padding to a multiple of 4
+    int32_t ns_pad;          // sphere records incl. never-hit padding to a multiple of 8
     int32_t hot_vec4;        // float4 count of the hot part (LDS bytes / 16)
     int32_t off_rect_hot;    // float4 offsets inside the image
     int32_t off_cyl_hot;

@@ -22,6 +22,7 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
                    size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant);
 void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream);
 int set_max_dynamic_lds(size_t bytes);
+bool variant_exists(unsigned variant);
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -87,7 +88,7 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     RenderParams &L = c.layout;
     memset(&L, 0, sizeof L);
     L.ns = (int)sph.size(), L.nr = (int)rec.size(), L.nc = (int)cyl.size(), L.nm = (int)s.mats.size();
-    L.ns_pad = (L.ns + 3) / 4 * 4;
+    L.ns_pad = (L.ns + 7) / 8 * 8;
     int off = 0;
     off += L.ns_pad + 4;  // sphere hot (+ never-hit padding)
     L.off_rect_hot = off;
@@ -285,7 +286,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     }
 
     const unsigned variant = o ? o->variant : 0;
-    if (variant > 3) {
+    if (!variant_exists(variant)) {
         set_error("unknown kernel variant %u", variant);
         return RT_ERR_ARG;
     }

@@ -40,6 +40,11 @@
 #include "philox.h"
 #include "../../include/rtmi.h"
 
+// minimum resident waves per SIMD the register allocator must leave room for (8 <=> 64 VGPRs)
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4
+#endif
+
 namespace rtmi {
 
 static constexpr float kTMin = 0.001f;  // main.cu:45 / main.cpp:22
@@ -73,9 +78,55 @@ __device__ __forceinline__ float rng_next(LaneRng &g, uint32_t k0, uint32_t k1) 
     return (float)(w >> 8) * (1.0f / 16777216.0f);
 }
 
+// Two / three consecutive uniforms with at most ONE block generation: lanes of a wave sit
+// at different stream positions, so every inlined refill site runs whenever any lane is at
+// a block boundary -- i.e. always.  Drawing groups costs one Philox per group, not per draw.
 template <bool COUNT>
-__device__ __forceinline__ float rng_pm1(LaneRng &g, uint32_t k0, uint32_t k1) {
-    return -1.0f + 2.0f * rng_next<COUNT>(g, k0, k1);
+__device__ __forceinline__ void rng_next2(LaneRng &g, uint32_t k0, uint32_t k1, float &u0, float &u1) {
+    const int pos = g.pos;  // 0..4 words already used of the current block
+    uint32_t w0, w1;
+    if (pos <= 2) {
+        w0 = pos == 0 ? g.b0 : (pos == 1 ? g.b1 : g.b2);
+        w1 = pos == 0 ? g.b1 : (pos == 1 ? g.b2 : g.b3);
+        g.pos = pos + 2;
+    } else {
+        const uint32_t last = g.b3;
+        Philox4 p = philox4x32_10(g.pixel, g.sample, g.block, 0u, k0, k1);
+        g.b0 = p.v[0], g.b1 = p.v[1], g.b2 = p.v[2], g.b3 = p.v[3];
+        g.block++;
+        w0 = pos == 3 ? last : g.b0;
+        w1 = pos == 3 ? g.b0 : g.b1;
+        g.pos = pos - 2;
+    }
+    if (COUNT) g.draws += 2;
+    u0 = (float)(w0 >> 8) * (1.0f / 16777216.0f);
+    u1 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void rng_next3(LaneRng &g, uint32_t k0, uint32_t k1, float &u0, float &u1, float &u2) {
+    const int pos = g.pos;
+    uint32_t w0, w1, w2;
+    if (pos <= 1) {
+        w0 = pos == 0 ? g.b0 : g.b1;
+        w1 = pos == 0 ? g.b1 : g.b2;
+        w2 = pos == 0 ? g.b2 : g.b3;
+        g.pos = pos + 3;
+    } else {
+        const uint32_t o2 = g.b2, o3 = g.b3;
+        Philox4 p = philox4x32_10(g.pixel, g.sample, g.block, 0u, k0, k1);
+        g.b0 = p.v[0], g.b1 = p.v[1], g.b2 = p.v[2], g.b3 = p.v[3];
+        g.block++;
+        // pos = 2: old b2, old b3, new b0 | pos = 3: old b3, new b0, new b1 | pos = 4: new b0..b2
+        w0 = pos == 2 ? o2 : (pos == 3 ? o3 : g.b0);
+        w1 = pos == 2 ? o3 : (pos == 3 ? g.b0 : g.b1);
+        w2 = pos == 2 ? g.b0 : (pos == 3 ? g.b1 : g.b2);
+        g.pos = pos - 1;
+    }
+    if (COUNT) g.draws += 3;
+    u0 = (float)(w0 >> 8) * (1.0f / 16777216.0f);
+    u1 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+    u2 = (float)(w2 >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -111,8 +162,10 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 //           / false: a lane only renders samples of its own pixel
 // PREFETCH: sphere records are read from LDS one batch of four ahead (default)
 //           / false: one record per iteration, waited for in place
-template <bool COUNT, bool POOL, bool PREFETCH>
-__global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
+// SCALAR:   the sphere table is read with wave-uniform loads from global memory (scalar
+//           cache -> SGPR operands) instead of LDS broadcast reads (experiment)
+template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR>
+__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
                                                      DevCounters *__restrict__ counters) {
     extern __shared__ float4 lds[];
@@ -140,7 +193,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
     unsigned long long *my_acc = tile_acc + wave * 192;
 
     const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
-    const float4 *sph = lds;
+    const float4 *sph = SCALAR ? image : lds;
     const float4 *rect = lds + P.off_rect_hot;
     const float4 *cyl = lds + P.off_cyl_hot;
     const int ns = P.ns, nr = P.nr, nc = P.nc;
@@ -196,14 +249,16 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
             if (start) {
                 cur_p = sp;
                 rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss);
-                float u = ((float)spx + rng_next<COUNT>(rng, k0, k1)) / wm1;
-                float v = ((float)spy + rng_next<COUNT>(rng, k0, k1)) / hm1;
+                float ju, jv;
+                rng_next2<COUNT>(rng, k0, k1, ju, jv);
+                float u = ((float)spx + ju) / wm1;
+                float v = ((float)spy + jv) / hm1;
                 float offx = 0.0f, offy = 0.0f, offz = 0.0f;
                 if (P.flags & RT_FLAG_DEFOCUS_BLUR) {
                     float px, py;
                     do {  // random_in_unit_disk, vec3.h:157-165
-                        px = rng_pm1<COUNT>(rng, k0, k1);
-                        py = rng_pm1<COUNT>(rng, k0, k1);
+                        rng_next2<COUNT>(rng, k0, k1, px, py);
+                        px = -1.0f + 2.0f * px, py = -1.0f + 2.0f * py;
                     } while (fmaf(px, px, py * py) >= 1.0f);
                     float rdx = P.cam.lens_radius * px, rdy = P.cam.lens_radius * py;
                     offx = fmaf(P.cam.u[0], rdx, P.cam.v[0] * rdy);
@@ -267,19 +322,25 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
         const float hb = dot3(ocx, ocy, ocz, dx, dy, dz);                                      \
         const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -S.w)));                 \
         const float disc = fmaf(hb, hb, -(ra * cc));                                           \
-        if (!(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f)) resolve(IDX, hb, disc);            \
+        const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
+        if (__builtin_expect(cand, 0)) resolve(IDX, hb, disc);                                 \
     }
             if (PREFETCH) {
-                // the table is padded to a multiple of 4 with never-hit records (r*r = -inf)
-                // plus 4 more, so fetching the next batch never leaves the table
-                float4 n0 = sph[0], n1 = sph[1], n2 = sph[2], n3 = sph[3];
-                for (int i = 0; i < P.ns_pad; i += 4) {
-                    const float4 s0 = n0, s1 = n1, s2 = n2, s3 = n3;
-                    n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7];
-                    RT_SPHERE_TEST(s0, i)
-                    RT_SPHERE_TEST(s1, i + 1)
-                    RT_SPHERE_TEST(s2, i + 2)
-                    RT_SPHERE_TEST(s3, i + 3)
+                // two register sets of four records, fetched one half-iteration ahead of their use;
+                // the table is padded to a multiple of 8 with never-hit records (r*r = -inf) plus 4
+                // more, so the fetches never leave the table
+                float4 a0 = sph[0], a1 = sph[1], a2 = sph[2], a3 = sph[3];
+                for (int i = 0; i < P.ns_pad; i += 8) {
+                    const float4 b0 = sph[i + 4], b1 = sph[i + 5], b2 = sph[i + 6], b3 = sph[i + 7];
+                    RT_SPHERE_TEST(a0, i)
+                    RT_SPHERE_TEST(a1, i + 1)
+                    RT_SPHERE_TEST(a2, i + 2)
+                    RT_SPHERE_TEST(a3, i + 3)
+                    a0 = sph[i + 8], a1 = sph[i + 9], a2 = sph[i + 10], a3 = sph[i + 11];
+                    RT_SPHERE_TEST(b0, i + 4)
+                    RT_SPHERE_TEST(b1, i + 5)
+                    RT_SPHERE_TEST(b2, i + 6)
+                    RT_SPHERE_TEST(b3, i + 7)
                 }
             } else {
 #pragma unroll 4
@@ -434,9 +495,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderParams P, const
                 float sx = 0, sy = 0, sz = 0, sl2 = 1;
                 if (kind <= MK_METAL) {
                     do {
-                        sx = rng_pm1<COUNT>(rng, k0, k1);
-                        sy = rng_pm1<COUNT>(rng, k0, k1);
-                        sz = rng_pm1<COUNT>(rng, k0, k1);
+                        rng_next3<COUNT>(rng, k0, k1, sx, sy, sz);
+                        sx = -1.0f + 2.0f * sx, sy = -1.0f + 2.0f * sy, sz = -1.0f + 2.0f * sz;
                         sl2 = dot3(sx, sy, sz, sx, sy, sz);
                     } while (sl2 >= 1.0f);
                 }
@@ -569,21 +629,41 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 }
 
 // launchers used by render_host.hip
+// X(variant id, POOL, PREFETCH, SCALAR): bit 0 = no tile pool, bit 1 = no prefetch,
+// bit 3 = sphere table through the scalar cache instead of LDS
+#define RT_VARIANT_TABLE(X)   \
+    X(0, true, true, false)   \
+    X(1, false, true, false)  \
+    X(2, true, false, false)  \
+    X(3, false, false, false) \
+    X(8, true, true, true)    \
+    X(10, true, false, true)
 void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, DevCounters *counters,
                    size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
     const float4 *img = (const float4 *)image;
     const dim3 g(grid), t(256);
     if (counters) {
-        hipLaunchKernelGGL((render_kernel<true, true, true>), g, t, lds_bytes, stream, P, img, acc, counters);
+        hipLaunchKernelGGL((render_kernel<true, true, true, false>), g, t, lds_bytes, stream, P, img, acc, counters);
         return;
     }
     DevCounters *none = nullptr;
-    switch (variant & 3u) {
-    case 0: hipLaunchKernelGGL((render_kernel<false, true, true>), g, t, lds_bytes, stream, P, img, acc, none); break;
-    case 1: hipLaunchKernelGGL((render_kernel<false, false, true>), g, t, lds_bytes, stream, P, img, acc, none); break;
-    case 2: hipLaunchKernelGGL((render_kernel<false, true, false>), g, t, lds_bytes, stream, P, img, acc, none); break;
-    default: hipLaunchKernelGGL((render_kernel<false, false, false>), g, t, lds_bytes, stream, P, img, acc, none); break;
+#define RT_LAUNCH(V, POOL, PRE, SCALAR)                                                          \
+    case V:                                                                                             \
+        hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR>), g, t, lds_bytes, stream, P, img, acc, none); \
+        break;
+    switch (variant) {
+        RT_VARIANT_TABLE(RT_LAUNCH)
+    default: break;
     }
+#undef RT_LAUNCH
+}
+
+bool variant_exists(unsigned variant) {
+#define RT_HAS(V, POOL, PRE, SCALAR) \
+    if (variant == V) return true;
+    RT_VARIANT_TABLE(RT_HAS)
+#undef RT_HAS
+    return false;
 }
 
 void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream) {
@@ -592,13 +672,15 @@ void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStr
 }
 
 int set_max_dynamic_lds(size_t bytes) {
-    const void *fns[5] = {reinterpret_cast<const void *>(&render_kernel<false, true, true>),
-                          reinterpret_cast<const void *>(&render_kernel<false, false, true>),
-                          reinterpret_cast<const void *>(&render_kernel<false, true, false>),
-                          reinterpret_cast<const void *>(&render_kernel<false, false, false>),
-                          reinterpret_cast<const void *>(&render_kernel<true, true, true>)};
-    for (const void *f : fns)
-        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, true, true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        return 1;
+#define RT_ATTR(V, POOL, PRE, SCALAR)                                                            \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false, POOL, PRE, SCALAR>), \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)      \
+        return 1;
+    RT_VARIANT_TABLE(RT_ATTR)
+#undef RT_ATTR
     return 0;
 }
 

@@ -124,10 +124,11 @@ def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
     assert np.abs(acc - whole).max() <= 13 * 2.0 ** -24 * max(1.0, acc.max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 8, 10])
 def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir, variant):
     """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
-    bit 1: unbatched sphere loop.  Same bits as the checker in every combination."""
+    bit 1: unbatched sphere loop; bit 3: sphere table read through the scalar cache instead of
+    LDS.  Same bits as the checker in every combination."""
     for name, w, h, spp in (("rtiow", 72, 40, 6), ("mixed_emissive", 50, 30, 5)):
         sc = _scene(rtmi, scenes_dir, golden_dir, name)
         sc.override(width=w, height=h, spp=spp)

@@ -7,9 +7,9 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for V in $VARS; do
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/v${V}_a -- python3 $R/tools/gpu_ab.py $SPP $V $CH > $OUT/v${V}_a.log 2>&1 || { echo fail a $V; tail -3 $OUT/v${V}_a.log; }
-  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH --output-format csv -d $OUT/v${V}_b -- python3 $R/tools/gpu_ab.py $SPP $V $CH > $OUT/v${V}_b.log 2>&1 || { echo fail b $V; tail -3 $OUT/v${V}_b.log; }
-  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/v${V}_c -- python3 $R/tools/gpu_ab.py $SPP $V $CH > $OUT/v${V}_c.log 2>&1 || { echo fail c $V; tail -3 $OUT/v${V}_c.log; }
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/v${V}_a -- python3 $R/tools/gpu_sweep.py $SPP $CH $V > $OUT/v${V}_a.log 2>&1 || { echo fail a $V; tail -3 $OUT/v${V}_a.log; }
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH --output-format csv -d $OUT/v${V}_b -- python3 $R/tools/gpu_sweep.py $SPP $CH $V > $OUT/v${V}_b.log 2>&1 || { echo fail b $V; tail -3 $OUT/v${V}_b.log; }
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/v${V}_c -- python3 $R/tools/gpu_sweep.py $SPP $CH $V > $OUT/v${V}_c.log 2>&1 || { echo fail c $V; tail -3 $OUT/v${V}_c.log; }
 done
 python3 - <<PY
 import csv,glob,collections
@@ -21,5 +21,5 @@ for V in "$VARS".split():
                 if 'render_kernel' in r['Kernel_Name'] and int(r['Grid_Size'])>1000000:
                     agg[r['Counter_Name']]+=float(r['Counter_Value'])
     # two timed launches + none small: normalise per launch (2 reps)
-    print("variant",V,{k:f"{v/2:.4g}" for k,v in sorted(agg.items())})
+    print("variant",V,{k:f"{v:.4g}" for k,v in sorted(agg.items())})
 PY
