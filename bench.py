@@ -180,10 +180,11 @@ def main():
             roof["valu_issue_peak_Tlane_inst"] = 78.6
         # algorithmic HBM bytes: framebuffer write once + scene image read once per workgroup (L2-resident)
         rows0 = scene.shard_rows(mine)
-        plane = rows0 * scene.width * 3 * 4
-        n_chunks = -(-scene.spp // chunk) if (chunk and chunk < scene.spp) else 1
-        # one chunk: the frame is written once; else partial sums written, re-read by the reducer, frame written
-        algo_bytes = plane if n_chunks == 1 else plane * (2 * n_chunks + 1)
+        plane = rows0 * scene.width * 3
+        n_chunks = -(-scene.spp // (chunk or 64))
+        # per launch: clear the 64-bit accumulators, one 8-byte atomic per pixel-channel and work item,
+        # read them back and write the fp32 frame
+        algo_bytes = plane * (8 + 8 * n_chunks + 8 + 4)
         roof["hbm_algorithmic_bytes"] = int(algo_bytes)
         roof["hbm_achieved_GBps"] = round(algo_bytes / (k_ms * 1e-3) / 1e9, 3)
         roof["hbm_frac"] = round(roof["hbm_achieved_GBps"] / PEAK_HBM_GBPS, 6)
@@ -211,9 +212,9 @@ def main():
 
 
 def default_chunk(spp: int) -> int:
-    """Samples per work-item.  One work-item per pixel (chunk = spp) leaves the chip short of
-    waves on a strong-scaled 1080p frame; a fixed chunk keeps results independent of N."""
-    return 128 if spp > 128 else 0  # measured: 2246 Msamples/s at 128 vs 1871 unchunked (1080p, 1024 spp)
+    """Samples per work item (8x8 tile x chunk, one wave): 0 = the library default (64).
+    Scheduling only -- the fixed-point pixel sums do not depend on it."""
+    return 0
 
 
 def cpu_baseline(rtmi, args):

@@ -193,13 +193,14 @@ typedef struct rt_opts {
     int32_t tile_rows;   /* 0 -> 8                                             */
     int32_t tile_first;
     int32_t tile_stride;
-    /* samples are summed in chunks of spp_chunk (each chunk in sample order by
-     * one work-item, chunk sums added in chunk order); 0 -> one chunk = all spp,
-     * i.e. the reference's plain in-order sum (main.cu:95-101).               */
+    /* samples per work item (one wave renders an 8x8 tile x spp_chunk samples at a time).
+     * Scheduling only: the per-pixel sum is exact (64-bit fixed point, 2^-32), so the
+     * framebuffer does not depend on it.  0 -> 64.                                  */
     int32_t spp_chunk;
     int32_t sample_first; /* render samples [sample_first, sample_first+count) */
     int32_t sample_count; /* 0 -> scene spp                                    */
-    uint32_t variant;     /* kernel variant selector, 0 = default (tuning A/B) */
+    uint32_t variant;     /* 0 = default kernel; ablation builds (same results): bit 0 strict
+                             one-lane-per-pixel, bit 1 no LDS prefetch, bit 3 scalar-cache table */
 } rt_opts;
 
 typedef struct rt_stats {

@@ -56,8 +56,9 @@ struct RenderParams {
     int32_t off_rect_cold;
     int32_t off_cyl_cold;
     int32_t off_mat;
-    int32_t blocks_x;        // workgroups per row band
+    int32_t tiles_x;         // 8-pixel tile columns
     int32_t bands;           // 8-row bands in the shard
+    int32_t num_items;       // work items = tiles_x * bands * num_chunks (one wave each)
 };
 
 struct DevCounters {

@@ -18,8 +18,9 @@
 
 namespace rtmi {
 
-void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, DevCounters *counters,
-                   size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant);
+void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
+                   DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant);
+int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes);
 void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream);
 int set_max_dynamic_lds(size_t bytes);
 bool variant_exists(unsigned variant);
@@ -41,6 +42,7 @@ struct DeviceEntry {
     unsigned long long *d_acc = nullptr;  // fixed-point pixel accumulators of the last launch
     size_t acc_bytes = 0;
     DevCounters *d_counters = nullptr;
+    int num_cus = 0;
 };
 
 struct DeviceSceneCache {
@@ -278,7 +280,9 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
 
     int sample_first = o ? o->sample_first : 0;
     int sample_count = (o && o->sample_count > 0) ? o->sample_count : s.spp;
-    int spp_chunk = (o && o->spp_chunk > 0 && o->spp_chunk < sample_count) ? o->spp_chunk : sample_count;
+    // samples per work item: scheduling only (the pixel sum is exact); 64 measured best on MI355X
+    int spp_chunk = (o && o->spp_chunk > 0) ? o->spp_chunk : 64;
+    if (spp_chunk > sample_count) spp_chunk = sample_count;
     int num_chunks = (sample_count + spp_chunk - 1) / spp_chunk;
     if (sample_first < 0) {
         set_error("sample_first must be >= 0");
@@ -369,7 +373,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     P.spp_chunk = spp_chunk, P.num_chunks = num_chunks;
     uint64_t seed = o ? o->seed : 0;
     P.seed_lo = (uint32_t)seed, P.seed_hi = (uint32_t)(seed >> 32);
-    P.blocks_x = (s.width + 31) / 32;
+    P.tiles_x = (s.width + 7) / 8;
     P.bands = (sh.local_rows + 7) / 8;
 
     const size_t lds_bytes = (size_t)P.hot_vec4 * 16 + 4 * 192 * sizeof(unsigned long long);
@@ -384,11 +388,21 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         return RT_ERR_HIP;
     }
     const size_t plane = (size_t)sh.local_rows * s.width * 3;
-    const unsigned long long grid64 = (unsigned long long)P.blocks_x * P.bands * num_chunks;
-    if (grid64 > 0x7fffffffull) {
-        set_error("launch of %llu workgroups exceeds the grid limit", grid64);
+    const unsigned long long items64 = (unsigned long long)P.tiles_x * P.bands * num_chunks;
+    if (items64 > 0x7fffffffull) {
+        set_error("%llu work items exceed the queue counter", items64);
         return RT_ERR_LIMIT;
     }
+    P.num_items = (int)items64;
+    // persistent launch: enough workgroups to fill the chip, never more than the work needs
+    if (ent->num_cus == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        ent->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const unsigned long long resident = (unsigned long long)ent->num_cus * blocks_per_cu(variant, count, lds_bytes);
+    const unsigned long long need_blocks = (items64 + 3) / 4;
+    const unsigned long long grid64 = need_blocks < resident ? (need_blocks ? need_blocks : 1) : resident;
 
     float *d_out = (float *)d_rgb_sum;
     DevCounters *d_cnt = nullptr;
@@ -404,7 +418,8 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         // while (depth > 0) never runs: every sample is black (main.cpp:20,42)
         HIP_TRY(hipMemsetAsync(d_out, 0, plane * sizeof(float), stream));
     } else {
-        const size_t need = plane * sizeof(unsigned long long);
+        // accumulators + the work-queue counter behind them, cleared together
+        const size_t need = plane * sizeof(unsigned long long) + 64;
         if (ent->acc_bytes < need) {
             if (ent->d_acc) HIP_TRY(hipFree(ent->d_acc));
             ent->d_acc = nullptr;
@@ -413,7 +428,8 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             ent->acc_bytes = need;
         }
         HIP_TRY(hipMemsetAsync(ent->d_acc, 0, need, stream));
-        launch_render(P, ent->d_image, ent->d_acc, d_cnt, lds_bytes, (unsigned)grid64, stream, variant);
+        unsigned int *d_queue = reinterpret_cast<unsigned int *>(ent->d_acc + plane);
+        launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, variant);
         launch_finalize(ent->d_acc, d_out, plane, stream);
         launches = 2;
     }

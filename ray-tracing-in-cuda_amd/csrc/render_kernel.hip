@@ -167,6 +167,7 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
+                                                     unsigned int *__restrict__ queue,
                                                      DevCounters *__restrict__ counters) {
     extern __shared__ float4 lds[];
     // stage the hot tables (hittable_list contents) into LDS
@@ -176,27 +177,37 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     for (int i = threadIdx.x; i < 4 * 64 * 3; i += 256) tile_acc[i] = 0ull;
     __syncthreads();
 
-    // workgroup -> (sample chunk, 8-row band of the shard, 32-pixel strip)
-    int b = blockIdx.x;
-    const int bx = b % P.blocks_x;
-    b /= P.blocks_x;
-    const int band = b % P.bands;
-    const int chunk = b / P.bands;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x0 = bx * 32 + wave * 8;
+    unsigned long long *my_acc = tile_acc + wave * 192;
+    const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
+    const float4 *sph = SCALAR ? image : lds;
+    const float4 *rect = lds + P.off_rect_hot;
+    const float4 *cyl = lds + P.off_cyl_hot;
+    const int ns = P.ns, nr = P.nr, nc = P.nc;
+    const float wm1 = (float)(P.width - 1), hm1 = (float)(P.height - 1);
+
+    uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
+    uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0, c_draws = 0;
+
+    // ---- persistent waves: the grid only fills the chip; every wave pulls (8x8 tile, sample
+    // chunk) work items from one global counter until it runs dry, so no CU idles behind a slow
+    // tile and the tail of a launch is one item, whatever the frame or shard size.  From here
+    // on the four waves of the workgroup never synchronise again.
+    for (;;) {
+    unsigned int item = 0;
+    if (lane == 0) item = atomicAdd(queue, 1u);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= (unsigned int)P.num_items) break;  // the counter only grows: every wave gets here
+    const int tx = (int)(item % (unsigned int)P.tiles_x);
+    const int band = (int)((item / (unsigned int)P.tiles_x) % (unsigned int)P.bands);
+    const int chunk = (int)(item / ((unsigned int)P.tiles_x * (unsigned int)P.bands));
+    const int x0 = tx * 8;
     // this lane's home pixel (the one it flushes at the end; with !POOL the one it renders)
     const int hx = x0 + (lane & 7);
     const int hlr = band * 8 + (lane >> 3);  // dense local row of this shard
     const int htl = hlr / P.tile_rows;
     const int hy = (P.tile_first + htl * P.tile_stride) * P.tile_rows + (hlr - htl * P.tile_rows);
     const int hvalid = (hx < P.width && hlr < P.local_rows && hy < P.height) ? 1 : 0;
-    unsigned long long *my_acc = tile_acc + wave * 192;
-
-    const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
-    const float4 *sph = SCALAR ? image : lds;
-    const float4 *rect = lds + P.off_rect_hot;
-    const float4 *cyl = lds + P.off_cyl_hot;
-    const int ns = P.ns, nr = P.nr, nc = P.nc;
 
     const int s_begin = P.sample_first + chunk * P.spp_chunk;
     int s_stop = s_begin + P.spp_chunk;
@@ -205,8 +216,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     const int pool_items = n_samples * 64;   // item k = (pixel k & 63, sample s_begin + (k >> 6))
     int cursor = 0;                          // POOL: wave-uniform pool cursor
     int mine = 0;                            // !POOL: samples of the home pixel started so far
-
-    const float wm1 = (float)(P.width - 1), hm1 = (float)(P.height - 1);
 
     LaneRng rng;
     rng.pixel = 0, rng.sample = 0, rng.block = 0, rng.pos = 4, rng.draws = 0;
@@ -217,9 +226,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     int depth = 0;
     int cur_p = lane;  // tile-local pixel of the path this lane is tracing
     bool active = false;
-
-    uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
-    uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0;
 
     for (;;) {
         // ---- refill: lanes without a live path take new samples
@@ -591,15 +597,20 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     }
 
     // ---- tile -> global accumulators (image[y*W + x] += res; one 64-bit atomic per channel:
-    // other sample chunks of the same pixels run in other workgroups)
+    // other sample chunks of the same pixels are other work items), and clear for the next item
     __builtin_amdgcn_wave_barrier();
-    if (hvalid) {
-        unsigned long long *g = acc + ((size_t)hlr * P.width + hx) * 3;
-        const unsigned long long *a = my_acc + lane * 3;
-        atomicAdd(g + 0, a[0]);
-        atomicAdd(g + 1, a[1]);
-        atomicAdd(g + 2, a[2]);
+    {
+        unsigned long long *a = my_acc + lane * 3;
+        if (hvalid) {
+            unsigned long long *g = acc + ((size_t)hlr * P.width + hx) * 3;
+            atomicAdd(g + 0, a[0]);
+            atomicAdd(g + 1, a[1]);
+            atomicAdd(g + 2, a[2]);
+        }
+        a[0] = a[1] = a[2] = 0ull;
     }
+    if (COUNT) c_draws += rng.draws;
+    }  // work items
 
     if (COUNT) {
         // one atomic per wave per counter
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         wave_add(&counters->scatter[1], c_scatter1);
         wave_add(&counters->scatter[2], c_scatter2);
         wave_add(&counters->scatter[3], c_scatter3);
-        wave_add(&counters->rng_draws, rng.draws);
+        wave_add(&counters->rng_draws, c_draws);
     }
 }
 
@@ -638,24 +649,40 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
     X(3, false, false, false) \
     X(8, true, true, true)    \
     X(10, true, false, true)
-void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, DevCounters *counters,
-                   size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
+void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
+                   DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
     const float4 *img = (const float4 *)image;
     const dim3 g(grid), t(256);
     if (counters) {
-        hipLaunchKernelGGL((render_kernel<true, true, true, false>), g, t, lds_bytes, stream, P, img, acc, counters);
+        hipLaunchKernelGGL((render_kernel<true, true, true, false>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
         return;
     }
     DevCounters *none = nullptr;
 #define RT_LAUNCH(V, POOL, PRE, SCALAR)                                                          \
     case V:                                                                                             \
-        hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR>), g, t, lds_bytes, stream, P, img, acc, none); \
+        hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR>), g, t, lds_bytes, stream, P, img, acc, queue, none); \
         break;
     switch (variant) {
         RT_VARIANT_TABLE(RT_LAUNCH)
     default: break;
     }
 #undef RT_LAUNCH
+}
+
+// resident workgroups per CU of a variant at this dynamic-LDS size (advisory; an over-estimate only
+// leaves late workgroups that find the queue empty)
+int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes) {
+    int n = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (count) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false>, 256, lds_bytes);
+    } else {
+#define RT_OCC(V, POOL, PRE, SCALAR) \
+    if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR>, 256, lds_bytes);
+        RT_VARIANT_TABLE(RT_OCC)
+#undef RT_OCC
+    }
+    return (e == hipSuccess && n > 0) ? n : 4;
 }
 
 bool variant_exists(unsigned variant) {
