@@ -1,0 +1,41 @@
+"""Turn a tools/profile.sh output directory into the committed summary under profiles/."""
+import collections, csv, glob, json, os, sys
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {"tag": tag, "source": "rocprofv3 (ROCm 7.2) on MI355X via tools/profile.sh", "kernel_stats": [], "pmc": {}}
+for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        out["kernel_stats"].append({k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        if "render_kernel" in r["Kernel_Name"]:
+            out["render_dispatch"] = {k: r[k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")}
+            break
+agg = collections.defaultdict(float); launches = collections.defaultdict(int)
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d): continue
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "render_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]] += float(r["Counter_Value"]); launches[r["Counter_Name"]] += 1
+out["pmc_workload"] = "bench.py --steps 1 --warmup 0 --spp 256 (RTIOW 1920x1080, one render_kernel launch per pass)"
+out["pmc"] = {k: agg[k] / max(1, launches[k]) for k in sorted(agg)}
+p = out["pmc"]
+d = {}
+if "SQ_THREAD_CYCLES_VALU" in p and "SQ_ACTIVE_INST_VALU" in p:
+    d["valu_lane_utilization"] = p["SQ_THREAD_CYCLES_VALU"] / (p["SQ_ACTIVE_INST_VALU"] * 64)
+if "GRBM_GUI_ACTIVE" in p and "SQ_INSTS_VALU" in p:
+    cyc = p["GRBM_GUI_ACTIVE"] / 8  # summed over 8 XCDs
+    d["kernel_cycles"] = cyc
+    d["valu_busy"] = p["SQ_INSTS_VALU"] / 1024 * 2 / cyc   # wave64 VALU = 2 cycles on a SIMD-32, 1024 SIMDs
+    if "SQ_WAVE_CYCLES" in p: d["avg_waves_per_simd"] = p["SQ_WAVE_CYCLES"] * 4 / (1024 * cyc)
+if "SQ_WAVE_CYCLES" in p:
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if k in p: d[k.lower() + "_frac_of_wave_cycles"] = p[k] / p["SQ_WAVE_CYCLES"]
+if "FETCH_SIZE" in p: d["hbm_read_bytes_per_launch"] = p["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE reads 1/2 (MI355X_MICROARCH.md HBM)
+if "WRITE_SIZE" in p: d["hbm_write_bytes_per_launch"] = p["WRITE_SIZE"] * 1024
+out["derived"] = d
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json"), "w"), indent=1)
+print(json.dumps(out["derived"], indent=1)); print(out.get("render_dispatch")); 
+for k in out["kernel_stats"][:4]: print(k["Name"][:70], k["Calls"], k["AverageNs"])
