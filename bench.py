@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,15 +87,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    dev_index = local_rank % ndev  # identity on a real N-GPU node; gloo rehearsals share GPUs
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     scene = rtmi.Scene.rtiow(7, args.width, args.height, args.spp, args.depth)
     chunk = args.chunk if args.chunk >= 0 else default_chunk(args.spp)
-    base = rtmi.Opts(seed=args.seed, device=local_rank, tile_rows=args.tile_rows, spp_chunk=chunk)
+    base = rtmi.Opts(seed=args.seed, device=dev_index, tile_rows=args.tile_rows, spp_chunk=chunk)
     mine = rdist.shard_opts(base, rank, world)
     local = rdist.alloc_local(scene, base, world, device)
     full = torch.empty((scene.height, scene.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
@@ -106,7 +114,7 @@ def main():
         scene.render_device(mine, local.data_ptr(), stream, st)
         if record:
             kernel_ms.append(st.kernel_ms)
-        return rdist.gather_framebuffer(local, scene, base, rank, world, out=full)
+        return rdist.gather_framebuffer(local, scene, base, rank, world, out=full, via_host=args.backend != "nccl")
 
     def barrier():
         if world > 1:
@@ -124,7 +132,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -149,7 +157,8 @@ def main():
         "config": {
             "workload": f"RTIOW random-spheres scene (rt_scene_rtiow seed 7, {scene.info.num_prims} spheres), "
                         f"{scene.width}x{scene.height}, {scene.spp} spp, depth {scene.max_depth}",
-            "sharding": f"row tiles of {args.tile_rows} rows interleaved over {world} rank(s), one gather to rank 0",
+            "sharding": f"row tiles of {args.tile_rows} rows interleaved over {world} rank(s), one gather to rank 0 "
+                        f"({args.backend})",
             "spp_chunk": chunk,
             "render_seed": args.seed,
         },

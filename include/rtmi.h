@@ -212,6 +212,7 @@ typedef struct rt_stats {
     uint64_t samples, queries, prim_tests, hits, misses;
     uint64_t scatter[4];  /* per rt_mat_type */
     uint64_t rng_draws;
+    uint64_t cand_lanes, cand_waves; /* sphere candidates that reached the sqrt block: lanes / wave entries */
 } rt_stats;
 
 void rt_opts_default(rt_opts *o);

@@ -65,6 +65,7 @@ struct DevCounters {
     unsigned long long samples, queries, prim_tests, hits, misses;
     unsigned long long scatter[4];
     unsigned long long rng_draws;
+    unsigned long long cand_lanes, cand_waves;  // sphere candidates resolved: per lane / per wave entry
 };
 
 }  // namespace rtmi

@@ -457,6 +457,8 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->misses = h.misses;
             for (int i = 0; i < 4; ++i) stats->scatter[i] = h.scatter[i];
             stats->rng_draws = h.rng_draws;
+            stats->cand_lanes = h.cand_lanes;
+            stats->cand_waves = h.cand_waves;
         }
     }
     return RT_OK;

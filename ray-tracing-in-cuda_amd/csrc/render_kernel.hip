@@ -42,7 +42,7 @@
 
 // minimum resident waves per SIMD the register allocator must leave room for (8 <=> 64 VGPRs)
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 4
+#define RT_WAVES_PER_SIMD 6
 #endif
 
 namespace rtmi {
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
     uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0, c_draws = 0;
+    uint32_t c_cand = 0, c_cand_wave = 0;
 
     // ---- persistent waves: the grid only fills the chip; every wave pulls (8x8 tile, sample
     // chunk) work items from one global counter until it runs dry, so no CU idles behind a slow
@@ -309,6 +310,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             // list entry, resolved through list_index_of), so the device table is sorted
             // big-spheres-first.
             auto resolve = [&](int idx, float hb, float disc) {
+                if (COUNT) {  // diagnostic: candidate lanes, and entries of this block per wave
+                    c_cand++;
+                    const unsigned long long em = __builtin_amdgcn_ballot_w64(true);
+                    if ((int)__builtin_ctzll(em) == lane) c_cand_wave++;
+                }
                 const float sq = sqrtf(disc);
                 float root = (-hb - sq) * rinv_a;
                 if (root < kTMin || best_t < root) root = (-hb + sq) * rinv_a;
@@ -628,6 +634,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         wave_add(&counters->scatter[2], c_scatter2);
         wave_add(&counters->scatter[3], c_scatter3);
         wave_add(&counters->rng_draws, c_draws);
+        wave_add(&counters->cand_lanes, c_cand);
+        wave_add(&counters->cand_waves, c_cand_wave);
     }
 }
 

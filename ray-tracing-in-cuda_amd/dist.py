@@ -38,9 +38,10 @@ def alloc_local(scene, base: Opts, world: int, device) -> torch.Tensor:
 
 
 def gather_framebuffer(local: torch.Tensor, scene, base: Opts, rank: int, world: int, dst: int = 0, group=None,
-                       out: torch.Tensor | None = None):
+                       out: torch.Tensor | None = None, via_host: bool = False):
     """One gather of every rank's (padded) local rows to `dst`; returns the assembled
-    (H, W, 3) image on dst, None elsewhere.  world == 1 needs no communication."""
+    (H, W, 3) image on dst, None elsewhere.  world == 1 needs no communication.
+    via_host: stage through host memory (gloo rehearsals of the multi-rank path)."""
     if world == 1:
         full = out if out is not None else torch.empty((scene.height, scene.width, 3), dtype=local.dtype,
                                                        device=local.device)
@@ -48,11 +49,14 @@ def gather_framebuffer(local: torch.Tensor, scene, base: Opts, rank: int, world:
         full.index_copy_(0, rows, local[: len(rows)])
         return full
     parts = None
+    send = local.cpu() if via_host else local
     if rank == dst:
-        parts = [torch.empty_like(local) for _ in range(world)]
-    dist.gather(local, gather_list=parts, dst=dst, group=group)
+        parts = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, gather_list=parts, dst=dst, group=group)
     if rank != dst:
         return None
+    if via_host:
+        parts = [p.to(local.device, non_blocking=True) for p in parts]
     full = out if out is not None else torch.empty((scene.height, scene.width, 3), dtype=local.dtype,
                                                    device=local.device)
     for r in range(world):
