@@ -183,9 +183,24 @@ def main():
             roof["frac"] = round(roof["achieved"] / PEAK_FP32_TFLOPS, 4)
             roof["flops_per_launch"] = flops
             roof["counts"] = {k: c[k] for k in ("samples", "queries", "prim_tests", "hits", "misses", "scatter",
-                                                "rng_draws")}
+                                                "rng_draws", "wave_queries", "clusters_visited", "groups_visited")}
             roof["tests_per_sample"] = round(c["prim_tests"] / max(1, c["samples"]), 1)
-            # issue-slot view: lane-instructions of the sphere test alone vs the VALU issue peak
+            roof["accounting"] = ("achieved = flops of the REFERENCE algorithm (linear hittable_list scan, "
+                                  "SURVEY 8(d)) / kernel time; the kernel skips sphere clusters whose AABB no "
+                                  "lane's ray reaches, so fewer tests are executed: see 'executed'")
+            # what the kernel actually executed (wave-level: every lane of a wave runs a visited test)
+            wq = c["wave_queries"]
+            sphere_wave_tests = wq * c["cull_prefix"] + c["clusters_visited"] * c["cull_cluster_size"]
+            box_wave_tests = wq * c["cull_groups"] + c["groups_visited"] * 4
+            ex_flops = (64 * (17 * sphere_wave_tests + 27 * box_wave_tests)
+                        + flops - sum(F_TEST[int(t)] for t in scene.prims()["type"]) * c["queries"])
+            roof["executed"] = {
+                "sphere_tests_per_sample": round(64 * sphere_wave_tests / max(1, c["samples"]), 1),
+                "box_tests_per_sample": round(64 * box_wave_tests / max(1, c["samples"]), 1),
+                "lane_occupancy_of_queries": round(c["queries"] / max(1, 64 * wq), 4),
+                "tflops": round(ex_flops / (k_ms * 1e-3) / 1e12, 3),
+                "frac": round(ex_flops / (k_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+            }
             roof["valu_issue_peak_Tlane_inst"] = 78.6
         # algorithmic HBM bytes: framebuffer write once + scene image read once per workgroup (L2-resident)
         rows0 = scene.shard_rows(mine)

@@ -200,7 +200,8 @@ typedef struct rt_opts {
     int32_t sample_first; /* render samples [sample_first, sample_first+count) */
     int32_t sample_count; /* 0 -> scene spp                                    */
     uint32_t variant;     /* 0 = default kernel; ablation builds (same results): bit 0 strict
-                             one-lane-per-pixel, bit 1 no LDS prefetch, bit 3 scalar-cache table */
+                             one-lane-per-pixel, bit 1 no LDS prefetch, bit 3 scalar-cache table,
+                             bit 4 no cluster culling (linear scan of every sphere) */
 } rt_opts;
 
 typedef struct rt_stats {
@@ -213,6 +214,10 @@ typedef struct rt_stats {
     uint64_t scatter[4];  /* per rt_mat_type */
     uint64_t rng_draws;
     uint64_t cand_lanes, cand_waves; /* sphere candidates that reached the sqrt block: lanes / wave entries */
+    uint64_t clusters_visited;       /* culling: sphere clusters a wave actually tested */
+    uint64_t wave_queries;           /* closest-hit queries executed, counted per WAVE */
+    uint64_t groups_visited;         /* culling: outer boxes that passed, per wave */
+    int32_t cull_prefix, cull_clusters, cull_groups, cull_cluster_size; /* table geometry */
 } rt_stats;
 
 void rt_opts_default(rt_opts *o);

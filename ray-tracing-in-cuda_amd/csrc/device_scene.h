@@ -2,8 +2,9 @@
 // part) and the kernel.  One contiguous buffer, 16-byte records:
 //
 //   HOT part (copied into LDS by every workgroup; everything the primitive loop reads)
-//     sphere  [ns_pad + 4]  1 x float4   {cx, cy, cz, r*r}   sorted by |r| descending, padded with
-//                                never-hit records (r*r = -inf) to a multiple of 8, plus 4 more
+//     sphere  [ns + 4]  1 x float4   {cx, cy, cz, r*r}   big spheres first, then Morton-ordered
+//                                clusters of 8; padded with never-hit records (r*r = -inf)
+//     box     [ncl] 2 x float4   inflated bounding box of each cluster (culling variant)
 //     rect    [nr]  2 x float4   {a0, a1, b0, b1} {k, axis(bits), 0, 0}
 //     cyl     [nc]  4 x float4   m_inv rows 0..2, {radius^2, zmin, zmax, 0}
 //   COLD part (stays in global memory / L2; read once per bounce by the winning lane)
@@ -18,6 +19,15 @@
 // root <= closest_so_far, gpu-version/object.cuh:23-37 with :61).
 #pragma once
 #include <stdint.h>
+
+// spheres per culling cluster (host packer and kernel agree on it)
+#ifndef RT_CLUSTER
+#define RT_CLUSTER 8
+#endif
+// consecutive clusters under one outer box
+#ifndef RT_GROUP
+#define RT_GROUP 4
+#endif
 
 namespace rtmi {
 
@@ -48,7 +58,12 @@ struct RenderParams {
     uint32_t seed_lo, seed_hi;
     // scene image
     int32_t ns, nr, nc, nm;
-    int32_t ns_pad;          // sphere records incl. never-hit padding to a multiple of 8
+    int32_t ns_pad;          // sphere slots incl. never-hit padding (= ns)
+    int32_t np;              // leading slots that are always tested (big spheres), multiple of 8
+    int32_t ncl;             // clusters of 8 slots after the prefix, each with a bounding box
+    int32_t off_box;         // 2 float4 per cluster: {min.xyz,_}, {max.xyz,_}
+    int32_t ngr, off_gbox;   // outer boxes over RT_GROUP consecutive clusters
+    float cull_extent1;      // 1 + max |coordinate| of the clustered spheres (per-lane box margin, see packer)
     int32_t hot_vec4;        // float4 count of the hot part (LDS bytes / 16)
     int32_t off_rect_hot;    // float4 offsets inside the image
     int32_t off_cyl_hot;
@@ -66,6 +81,9 @@ struct DevCounters {
     unsigned long long scatter[4];
     unsigned long long rng_draws;
     unsigned long long cand_lanes, cand_waves;  // sphere candidates resolved: per lane / per wave entry
+    unsigned long long clusters_visited;         // culling: clusters whose spheres were tested (per wave)
+    unsigned long long groups_visited;           // culling: outer boxes that passed (per wave)
+    unsigned long long wave_queries;             // closest-hit queries executed per wave (loop iterations)
 };
 
 }  // namespace rtmi

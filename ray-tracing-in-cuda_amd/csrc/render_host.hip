@@ -82,24 +82,79 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         default: rec.push_back((int)i); break;
         }
     }
-    // big spheres first: they are the likeliest closest hits, which makes the kernel's
-    // "farther than the current best" reject effective early (order does not change results)
+    // Sphere slots.  The closest hit does not depend on the visiting order (ties are resolved
+    // through the stored list index), so the table is laid out for the kernel:
+    //   prefix   : the big spheres (|r| > 4 x median), largest first -- the likeliest closest
+    //              hits, tested unconditionally, so best_t is tight before anything else;
+    //   clusters : the rest in Morton order of their centres, 8 per cluster, each cluster with a
+    //              bounding box (the slab test of aabb.hpp) the culling variant tests first.
+    // Both parts are padded to multiples of 8 with never-hit records (r*r = -inf), plus 4 more.
     std::stable_sort(sph.begin(), sph.end(), [&](int a, int b) {
         return std::fabs(s.prims[a].f[3]) > std::fabs(s.prims[b].f[3]);
     });
+    std::vector<int> slots;  // prim index per slot, -1 = padding
+    int n_prefix = (int)sph.size();
+    if (sph.size() > 16) {
+        std::vector<float> radii;
+        for (int i : sph) radii.push_back(std::fabs(s.prims[i].f[3]));
+        std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+        const float big = 4.0f * radii[radii.size() / 2];
+        n_prefix = 0;
+        while (n_prefix < (int)sph.size() && std::fabs(s.prims[sph[n_prefix]].f[3]) > big) ++n_prefix;
+    }
+    for (int k = 0; k < n_prefix; ++k) slots.push_back(sph[k]);
+    while (slots.size() % 8) slots.push_back(-1);
+    const int np_slots = (int)slots.size();
+    std::vector<int> rest(sph.begin() + n_prefix, sph.end());
+    if (!rest.empty()) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i : rest)
+            for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], s.prims[i].f[a]), hi[a] = std::max(hi[a], s.prims[i].f[a]);
+        auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FFu;
+            v = (v | (v << 8)) & 0x0300F00Fu;
+            v = (v | (v << 4)) & 0x030C30C3u;
+            v = (v | (v << 2)) & 0x09249249u;
+            return v;
+        };
+        auto morton = [&](int i) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; ++a) {
+                float ext = hi[a] - lo[a];
+                float t = ext > 0 ? (s.prims[i].f[a] - lo[a]) / ext : 0.0f;
+                q[a] = (uint32_t)std::min(1023.0f, std::max(0.0f, t * 1023.0f));
+            }
+            return spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        };
+        std::stable_sort(rest.begin(), rest.end(), [&](int a, int b) { return morton(a) < morton(b); });
+    }
+    for (int i : rest) slots.push_back(i);
+    while ((slots.size() - np_slots) % RT_CLUSTER) slots.push_back(-1);
+    const int n_clusters = ((int)slots.size() - np_slots) / RT_CLUSTER;
+    while (slots.size() % 8) slots.push_back(-1);  // the flat scan walks 8 slots per iteration
+    const int ns_slots = (int)slots.size();
+
     RenderParams &L = c.layout;
     memset(&L, 0, sizeof L);
-    L.ns = (int)sph.size(), L.nr = (int)rec.size(), L.nc = (int)cyl.size(), L.nm = (int)s.mats.size();
-    L.ns_pad = (L.ns + 7) / 8 * 8;
+    L.ns = ns_slots, L.nr = (int)rec.size(), L.nc = (int)cyl.size(), L.nm = (int)s.mats.size();
+    L.ns_pad = ns_slots;
+    L.np = np_slots;
+    L.ncl = n_clusters;
     int off = 0;
-    off += L.ns_pad + 4;  // sphere hot (+ never-hit padding)
+    off += ns_slots + 4;  // sphere hot (+ never-hit padding)
+    L.off_box = off;
+    off += 2 * n_clusters;
+    const int n_groups = (n_clusters + RT_GROUP - 1) / RT_GROUP;  // RT_GROUP consecutive clusters share an outer box
+    L.ngr = n_groups;
+    L.off_gbox = off;
+    off += 2 * n_groups;
     L.off_rect_hot = off;
     off += 2 * L.nr;
     L.off_cyl_hot = off;
     off += 4 * L.nc;
     L.hot_vec4 = off;
     L.off_sph_cold = off;
-    off += L.ns;
+    off += ns_slots;
     L.off_rect_cold = off;
     off += L.nr;
     L.off_cyl_cold = off;
@@ -110,16 +165,61 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     float *I = c.image.data();
     auto rec4 = [&](int idx) { return I + (size_t)idx * 4; };
 
-    for (int k = L.ns; k < L.ns_pad + 4; ++k) rec4(k)[3] = -INFINITY;  // c = +inf, disc = -inf: never a candidate
-    for (int k = 0; k < L.ns; ++k) {
-        const rt_prim &p = s.prims[sph[k]];
+    for (int k = 0; k < ns_slots + 4; ++k) {
         float *h = rec4(k);
+        const int pi = k < ns_slots ? slots[k] : -1;
+        if (pi < 0) {
+            h[3] = -INFINITY;  // c = +inf, disc = -inf: never a candidate
+            continue;
+        }
+        const rt_prim &p = s.prims[pi];
         h[0] = p.f[0], h[1] = p.f[1], h[2] = p.f[2];
         h[3] = p.f[3] * p.f[3];  // r*r in fp32, as sphere::hit evaluates it
         float *cd = rec4(L.off_sph_cold + k);
         cd[0] = 1.0f / p.f[3];   // (p - c) / r  ==  (1/r) * (p - c), vec3.cuh:105
         cd[1] = bits(p.material);
-        cd[2] = bits(sph[k]);
+        cd[2] = bits(pi);
+    }
+    // Cluster boxes.  Skipping a cluster must never change the result of the fp32 sphere test, whose
+    // rounding error grows with the distance |oc| from the ray origin to the sphere: with unit
+    // roundoff e = 2^-24, |disc_fp32 - disc| <= 15 e a |oc|^2, so a ray the test can accept passes
+    // within r + sqrt(15 e)|oc| ~ r + 1e-3 |oc| of the centre, and its fp32 root lies within the same
+    // distance of that approach point: the hit point is inside the sphere's box grown by 2e-3 |oc|.
+    // |oc| <= sqrt(3) (max|o_i| + extent), so the KERNEL grows every box per lane by
+    //     m = 4e-3 (max|o_i| + extent + 1)
+    // (two shifted ray origins per query, no extra work per box); a ray that leaked 2000 units
+    // inside the ground sphere thereby visits everything, exactly like the noise it would hit.
+    // The stored boxes only carry a 1e-5-relative pad for their own rounding.
+    float extent = 0.0f;  // max |coordinate| reached by a clustered sphere
+    for (int k = np_slots; k < (int)slots.size(); ++k) {
+        if (slots[k] < 0) continue;
+        const rt_prim &p = s.prims[slots[k]];
+        for (int a = 0; a < 3; ++a) extent = std::max(extent, std::fabs(p.f[a]) + std::fabs(p.f[3]));
+    }
+    L.cull_extent1 = extent + 1.0f;
+    const float inflate = 1e-5f * (extent + 1.0f);
+    for (int q = 0; q < n_clusters; ++q) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < RT_CLUSTER; ++k) {
+            const int pi = slots[np_slots + RT_CLUSTER * q + k];
+            if (pi < 0) continue;
+            const rt_prim &p = s.prims[pi];
+            const float r = std::fabs(p.f[3]);
+            for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], p.f[a] - r), hi[a] = std::max(hi[a], p.f[a] + r);
+        }
+        float *b = rec4(L.off_box + 2 * q);
+        for (int a = 0; a < 3; ++a) {
+            b[a] = lo[a] - inflate;
+            b[4 + a] = hi[a] + inflate;
+        }
+    }
+    for (int g = 0; g < n_groups; ++g) {  // outer boxes: union of the (already inflated) cluster boxes
+        float *gb = rec4(L.off_gbox + 2 * g);
+        for (int a = 0; a < 3; ++a) gb[a] = INFINITY, gb[4 + a] = -INFINITY;
+        for (int q = g * RT_GROUP; q < std::min(n_clusters, (g + 1) * RT_GROUP); ++q) {
+            const float *b = rec4(L.off_box + 2 * q);
+            for (int a = 0; a < 3; ++a) gb[a] = std::min(gb[a], b[a]), gb[4 + a] = std::max(gb[4 + a], b[4 + a]);
+        }
     }
     for (int k = 0; k < L.nr; ++k) {
         const rt_prim &p = s.prims[rec[k]];
@@ -459,6 +559,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->rng_draws = h.rng_draws;
             stats->cand_lanes = h.cand_lanes;
             stats->cand_waves = h.cand_waves;
+            stats->clusters_visited = h.clusters_visited;
+            stats->groups_visited = h.groups_visited;
+            stats->wave_queries = h.wave_queries;
+            stats->cull_prefix = P.np, stats->cull_clusters = P.ncl, stats->cull_groups = P.ngr;
+            stats->cull_cluster_size = RT_CLUSTER;
         }
     }
     return RT_OK;

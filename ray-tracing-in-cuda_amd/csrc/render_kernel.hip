@@ -164,7 +164,10 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 //           / false: one record per iteration, waited for in place
 // SCALAR:   the sphere table is read with wave-uniform loads from global memory (scalar
 //           cache -> SGPR operands) instead of LDS broadcast reads (experiment)
-template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR>
+// CULL:     after the always-tested big spheres, clusters of 8 spheres are visited only if some
+//           lane's ray passes the cluster's (inflated) bounding box: slab test of aabb.hpp:15-29
+//           + __any.  Conservative, so results are unchanged; fewer tests are executed.
+template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, bool CULL>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
                                                      unsigned int *__restrict__ queue,
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
     uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0, c_draws = 0;
-    uint32_t c_cand = 0, c_cand_wave = 0;
+    uint32_t c_cand = 0, c_cand_wave = 0, c_clusters = 0, c_groups = 0, c_wave_queries = 0;
 
     // ---- persistent waves: the grid only fills the chip; every wave pulls (8x8 tile, sample
     // chunk) work items from one global counter until it runs dry, so no CU idles behind a slow
@@ -337,12 +340,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
         if (__builtin_expect(cand, 0)) resolve(IDX, hb, disc);                                 \
     }
+            const int n_scan = CULL ? P.np : P.ns_pad;  // slots tested unconditionally
             if (PREFETCH) {
                 // two register sets of four records, fetched one half-iteration ahead of their use;
                 // the table is padded to a multiple of 8 with never-hit records (r*r = -inf) plus 4
                 // more, so the fetches never leave the table
                 float4 a0 = sph[0], a1 = sph[1], a2 = sph[2], a3 = sph[3];
-                for (int i = 0; i < P.ns_pad; i += 8) {
+                for (int i = 0; i < n_scan; i += 8) {
                     const float4 b0 = sph[i + 4], b1 = sph[i + 5], b2 = sph[i + 6], b3 = sph[i + 7];
                     RT_SPHERE_TEST(a0, i)
                     RT_SPHERE_TEST(a1, i + 1)
@@ -356,9 +360,48 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 }
             } else {
 #pragma unroll 4
-                for (int i = 0; i < ns; ++i) {
+                for (int i = 0; i < n_scan; ++i) {
                     const float4 s = sph[i];
                     RT_SPHERE_TEST(s, i)
+                }
+            }
+            if (CULL) {
+                // clusters: aabb::hit (aabb.hpp:15-29) for every live lane, then one wave-wide vote
+                const float idx = 1.0f / dx, idy = 1.0f / dy, idz = 1.0f / dz;
+                // per-lane box margin covering the fp32 error of the sphere test at this origin's
+                // distance (derivation in render_host.hip): two shifted origins, nothing per box
+                const float marg = 4e-3f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + P.cull_extent1);
+                const float oxm = ox + marg, oym = oy + marg, ozm = oz + marg;
+                const float oxp = ox - marg, oyp = oy - marg, ozp = oz - marg;
+                const float4 *box = lds + P.off_box;
+                const float4 *gbox = lds + P.off_gbox;
+                auto slab_live = [&](const float4 bmn, const float4 bmx) -> bool {
+                    const float lx = (bmn.x - oxm) * idx, ux = (bmx.x - oxp) * idx;
+                    const float ly = (bmn.y - oym) * idy, uy = (bmx.y - oyp) * idy;
+                    const float lz = (bmn.z - ozm) * idz, uz = (bmx.z - ozp) * idz;
+                    const float tn = fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), fminf(lz, uz));
+                    const float tf = fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), fmaxf(lz, uz));
+                    // dead: (grown) box missed, behind the origin, or entirely beyond the current best
+                    // hit (1e-4 relative slack on top of the margin).  NaN -> live.
+                    return !(tn > tf) && !(tf < 0.0f) && !(tn > best_t * 1.0001f);
+                };
+                for (int g = 0; g < P.ngr; ++g) {
+                if (__builtin_amdgcn_ballot_w64(slab_live(gbox[2 * g], gbox[2 * g + 1])) == 0ull) continue;
+                if (COUNT) c_groups++;
+                const int q_end = min(P.ncl, (g + 1) * RT_GROUP);
+                for (int q = g * RT_GROUP; q < q_end; ++q) {
+                    const bool live = slab_live(box[2 * q], box[2 * q + 1]);
+                    if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
+                        const int base = P.np + RT_CLUSTER * q;
+                        const float4 *cs = sph + base;
+                        float4 rec[RT_CLUSTER];
+#pragma unroll
+                        for (int k = 0; k < RT_CLUSTER; ++k) rec[k] = cs[k];
+#pragma unroll
+                        for (int k = 0; k < RT_CLUSTER; ++k) RT_SPHERE_TEST(rec[k], base + k)
+                        if (COUNT) c_clusters++;
+                    }
+                }
                 }
             }
 #undef RT_SPHERE_TEST
@@ -439,7 +482,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     }
                 }
             }
-            if (COUNT) c_queries++;
+            if (COUNT) {
+                c_queries++;
+                if ((int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) == lane) c_wave_queries++;
+            }
 
             // ---- shade the winner (ray_color body, main.cu:45-65 / main.cpp:22-38)
             bool path_done = false;
@@ -636,6 +682,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         wave_add(&counters->rng_draws, c_draws);
         wave_add(&counters->cand_lanes, c_cand);
         wave_add(&counters->cand_waves, c_cand_wave);
+        if (lane == 0 && c_clusters) atomicAdd(&counters->clusters_visited, (unsigned long long)c_clusters);
+        if (lane == 0 && c_groups) atomicAdd(&counters->groups_visited, (unsigned long long)c_groups);
+        wave_add(&counters->wave_queries, c_wave_queries);
     }
 }
 
@@ -648,27 +697,31 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 }
 
 // launchers used by render_host.hip
-// X(variant id, POOL, PREFETCH, SCALAR): bit 0 = no tile pool, bit 1 = no prefetch,
-// bit 3 = sphere table through the scalar cache instead of LDS
-#define RT_VARIANT_TABLE(X)   \
-    X(0, true, true, false)   \
-    X(1, false, true, false)  \
-    X(2, true, false, false)  \
-    X(3, false, false, false) \
-    X(8, true, true, true)    \
-    X(10, true, false, true)
+// X(variant id, POOL, PREFETCH, SCALAR, CULL).  0 is the product default; the others are ablations
+// with identical results: bit 0 = no tile pool (strict one-lane-per-pixel), bit 1 = no LDS prefetch,
+// bit 3 = sphere table through the scalar cache instead of LDS, bit 4 = no cluster culling (every
+// sphere tested for every query: the reference's linear hittable_list scan)
+#define RT_VARIANT_TABLE(X)          \
+    X(0, true, true, false, true)    \
+    X(1, false, true, false, true)   \
+    X(2, true, false, false, true)   \
+    X(8, true, true, true, true)     \
+    X(16, true, true, false, false)  \
+    X(17, false, true, false, false) \
+    X(19, false, false, false, false) \
+    X(24, true, true, true, false)
 void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
                    DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
     const float4 *img = (const float4 *)image;
     const dim3 g(grid), t(256);
     if (counters) {
-        hipLaunchKernelGGL((render_kernel<true, true, true, false>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
+        hipLaunchKernelGGL((render_kernel<true, true, true, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
         return;
     }
     DevCounters *none = nullptr;
-#define RT_LAUNCH(V, POOL, PRE, SCALAR)                                                          \
+#define RT_LAUNCH(V, POOL, PRE, SCALAR, CULL)                                                          \
     case V:                                                                                             \
-        hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR>), g, t, lds_bytes, stream, P, img, acc, queue, none); \
+        hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL>), g, t, lds_bytes, stream, P, img, acc, queue, none); \
         break;
     switch (variant) {
         RT_VARIANT_TABLE(RT_LAUNCH)
@@ -683,10 +736,10 @@ int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes) {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
     if (count) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false>, 256, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, true>, 256, lds_bytes);
     } else {
-#define RT_OCC(V, POOL, PRE, SCALAR) \
-    if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR>, 256, lds_bytes);
+#define RT_OCC(V, POOL, PRE, SCALAR, CULL) \
+    if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL>, 256, lds_bytes);
         RT_VARIANT_TABLE(RT_OCC)
 #undef RT_OCC
     }
@@ -694,7 +747,7 @@ int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes) {
 }
 
 bool variant_exists(unsigned variant) {
-#define RT_HAS(V, POOL, PRE, SCALAR) \
+#define RT_HAS(V, POOL, PRE, SCALAR, CULL) \
     if (variant == V) return true;
     RT_VARIANT_TABLE(RT_HAS)
 #undef RT_HAS
@@ -707,11 +760,11 @@ void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStr
 }
 
 int set_max_dynamic_lds(size_t bytes) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, true, true, false>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, true, true, false, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
         return 1;
-#define RT_ATTR(V, POOL, PRE, SCALAR)                                                            \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false, POOL, PRE, SCALAR>), \
+#define RT_ATTR(V, POOL, PRE, SCALAR, CULL)                                                            \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false, POOL, PRE, SCALAR, CULL>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)      \
         return 1;
     RT_VARIANT_TABLE(RT_ATTR)
