@@ -183,8 +183,8 @@ int rt_scene_get_textures(const rt_scene *s, rt_texture *out, int cap);   /* -> 
 /* ---- render ------------------------------------------------------------ */
 
 typedef struct rt_opts {
-    uint64_t seed;       /* Philox key; the reference seeds curand with the pixel
-                            id (main.cu:120-125)                               */
+    uint64_t seed;       /* Philox key that seeds every (pixel, sample) stream; the
+                            reference seeds curand with the pixel id (main.cu:120-125) */
     int32_t device;      /* HIP device ordinal                                 */
     /* row-tile shard (multi-GPU): this call renders the row tiles
      *   t = tile_first, tile_first + tile_stride, ...   (< ceil(H / tile_rows))
@@ -266,8 +266,11 @@ const char *rt_status_string(int status);
 int rt_abi_version(void);
 /* number of usable gfx950 devices, or -rt_status */
 int rt_device_count(void);
-/* Philox4x32-10 block (the stream the kernel draws from), for known-answer tests */
+/* Philox4x32-10 block (seeds every (pixel, sample) stream), for known-answer tests */
 void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* first n raw 32-bit words of the xorshift128 stream of one (pixel, sample); the kernel's
+ * uniforms are (word >> 8) * 2^-24 */
+void rt_sample_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t *out, int n);
 /* slab test, gpu-version/aabb.hpp:15-29 (host evaluation of the device helper's formula) */
 int rt_aabb_hit(const float bmin[3], const float bmax[3], const float orig[3], const float dir[3],
                 float t_min, float t_max);

@@ -6,8 +6,8 @@
 // /root/reference -- nothing is copied into this repo; the Makefile passes the
 // directory with -I -- and drives them deterministically:
 //
-//   * rand() is macro-hooked to a thread-local Philox4x32-10 stream keyed by
-//     (seed; pixel, sample), and RAND_MAX is redefined to 2^24-1, so the
+//   * rand() is macro-hooked to a thread-local stream per (seed; pixel, sample)
+//     (Philox4x32-10 block -> xorshift128), and RAND_MAX is redefined to 2^24-1, so the
 //     reference's  rand() / double(int(RAND_MAX)+1)  (rtweekend.h:23) yields
 //     exactly the 24-bit uniforms the HIP kernel and rt_oracle.c consume.
 //     (The stock expression overflows with glibc's RAND_MAX = 2^31-1; the hook
@@ -41,16 +41,16 @@
 
 // ---- the hook -----------------------------------------------------------------
 namespace {
+// the stream of one (pixel, sample): Philox4x32-10 block -> xorshift128 state (same as
+// ray-tracing-in-cuda_amd/csrc/philox.h and rt_oracle.c; written out again here on purpose)
 struct HookRng {
-    uint32_t k0, k1, pixel, sample, block;
-    uint32_t buf[4];
-    int pos;
+    uint32_t x, y, z, w;
     uint64_t draws;
 };
-thread_local HookRng g_rng = {0, 0, 0, 0, 0, {0, 0, 0, 0}, 4, 0};
+thread_local HookRng g_rng = {0, 0, 0, 1, 0};
 
-void hook_block(HookRng &g) {
-    uint32_t c0 = g.pixel, c1 = g.sample, c2 = g.block, c3 = 0, k0 = g.k0, k1 = g.k1;
+void hook_seed(uint64_t seed, uint32_t pixel, uint32_t sample) {
+    uint32_t c0 = pixel, c1 = sample, c2 = 0, c3 = 0, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -62,25 +62,19 @@ void hook_block(HookRng &g) {
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    g.buf[0] = c0, g.buf[1] = c1, g.buf[2] = c2, g.buf[3] = c3;
-    g.block++;
-    g.pos = 0;
-}
-void hook_seed(uint64_t seed, uint32_t pixel, uint32_t sample) {
-    g_rng.k0 = (uint32_t)seed;
-    g_rng.k1 = (uint32_t)(seed >> 32);
-    g_rng.pixel = pixel;
-    g_rng.sample = sample;
-    g_rng.block = 0;
-    g_rng.pos = 4;
+    g_rng.x = c0, g_rng.y = c1, g_rng.z = c2, g_rng.w = c3;
+    if ((c0 | c1 | c2 | c3) == 0u) g_rng.w = 0x9E3779B9u;
     g_rng.draws = 0;
 }
 }  // namespace
 
 int rt_ref_hook() {
-    if (g_rng.pos == 4) hook_block(g_rng);
-    g_rng.draws++;
-    return (int)(g_rng.buf[g_rng.pos++] >> 8);
+    HookRng &g = g_rng;
+    uint32_t t = g.x ^ (g.x << 11);
+    g.x = g.y, g.y = g.z, g.z = g.w;
+    g.w = g.w ^ (g.w >> 19) ^ (t ^ (t >> 8));
+    g.draws++;
+    return (int)(g.w >> 8);
 }
 
 #undef RAND_MAX

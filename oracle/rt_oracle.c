@@ -42,8 +42,9 @@
 
 /* ------------------------------------------------------------------ RNG
  * Replaces cpu/rtweekend.h:17-29 random_double() (one global rand() stream) and
- * gpu/rtweekend.cuh:23-29 (curand XORWOW per pixel).  Philox4x32-10, key = seed,
- * counter = (pixel id, sample index, block, 0); a uniform is the top 24 bits.
+ * gpu/rtweekend.cuh:23-29 (curand XORWOW per pixel).  Philox4x32-10 with key = seed and
+ * counter = (pixel id, sample index, 0, 0) seeds a xorshift128 stream per sample; a
+ * uniform is the top 24 bits of a word.
  * Restated from the published algorithm (Salmon, Moraes, Dror, Shaw: "Parallel
  * random numbers: as easy as 1, 2, 3", SC'11); known-answer vectors from the
  * Random123 distribution are checked in tests/test_philox.py. */
@@ -67,36 +68,42 @@ void rto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     philox_block(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
 
+/* Each (pixel, sample) owns a xorshift128 generator (Marsaglia, "Xorshift RNGs", JSS 2003,
+ * xor128) whose 128-bit state is one Philox block keyed by the seed. */
 typedef struct rng_t {
-    uint32_t k0, k1, pixel, sample, block;
-    uint32_t buf[4];
-    int pos;
+    uint32_t x, y, z, w;
     uint64_t draws;
 } rng_t;
 
 static void rng_init(rng_t *g, uint64_t seed, uint32_t pixel, uint32_t sample) {
-    g->k0 = (uint32_t)seed;
-    g->k1 = (uint32_t)(seed >> 32);
-    g->pixel = pixel;
-    g->sample = sample;
-    g->block = 0;
-    g->pos = 4;
+    uint32_t b[4];
+    philox_block(pixel, sample, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), b);
+    g->x = b[0], g->y = b[1], g->z = b[2], g->w = b[3];
+    if ((g->x | g->y | g->z | g->w) == 0u) g->w = 0x9E3779B9u; /* all-zero is a fixed point */
     g->draws = 0;
+}
+
+static uint32_t rng_word(rng_t *g) {
+    uint32_t t = g->x ^ (g->x << 11);
+    g->x = g->y, g->y = g->z, g->z = g->w;
+    g->w = g->w ^ (g->w >> 19) ^ (t ^ (t >> 8));
+    return g->w;
 }
 
 /* random_double(), cpu/rtweekend.h:17-25: uniform in [0,1) */
 static float random_float(rng_t *g) {
-    if (g->pos == 4) {
-        philox_block(g->pixel, g->sample, g->block, 0u, g->k0, g->k1, g->buf);
-        g->block++;
-        g->pos = 0;
-    }
     g->draws++;
-    return (float)(g->buf[g->pos++] >> 8) * (1.0f / 16777216.0f);
+    return (float)(rng_word(g) >> 8) * (1.0f / 16777216.0f);
 }
 
 /* random_double(min,max), cpu/rtweekend.h:27-29, for (-1,1): -1 + 2*xi (exact) */
 static float random_pm1(rng_t *g) { return -1.0f + 2.0f * random_float(g); }
+
+void rto_sample_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t *out, int n) {
+    rng_t g;
+    rng_init(&g, seed, pixel, sample);
+    for (int i = 0; i < n; ++i) out[i] = rng_word(&g);
+}
 
 /* ------------------------------------------------------------------ vec3
  * cpu/vec3.h:9-118 (class vec3 and free operators), fp32 */

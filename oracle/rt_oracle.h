@@ -87,6 +87,7 @@ int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_fir
                int sample_count, int spp_chunk, float *rgb_sum, rto_counts *counts, int threads);
 
 void rto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void rto_sample_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t *out, int n);
 int rto_aabb_hit(const float bmin[3], const float bmax[3], const float orig[3],
                  const float dir[3], float t_min, float t_max);
 /* PPM quantisation of one channel sum: int(256*clamp(sqrt(sum/spp),0,0.999)) */

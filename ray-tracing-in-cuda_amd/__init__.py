@@ -159,6 +159,7 @@ _sig("rt_write_ppm", C.c_int, C.c_char_p, _p, C.c_int, C.c_int, C.c_int)
 _sig("rt_quantize_rgb8", C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p)
 _sig("rt_philox4x32_10", None, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 _sig("rt_aabb_hit", C.c_int, _f3, _f3, _f3, _f3, C.c_float, C.c_float)
+_sig("rt_sample_stream", None, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int)
 
 C_SYMBOLS = [
     "rt_last_error", "rt_status_string", "rt_abi_version", "rt_device_count", "rt_opts_default",
@@ -169,7 +170,7 @@ C_SYMBOLS = [
     "rt_scene_override", "rt_scene_get_info", "rt_scene_get_camera", "rt_scene_get_prims",
     "rt_scene_get_materials", "rt_scene_get_textures", "rt_shard_rows", "rt_shard_global_row",
     "rt_render_hip_device", "rt_render_hip", "rt_render_hip_count", "rt_shard_scatter_rows", "rt_write_ppm",
-    "rt_quantize_rgb8", "rt_philox4x32_10", "rt_aabb_hit",
+    "rt_quantize_rgb8", "rt_philox4x32_10", "rt_aabb_hit", "rt_sample_stream",
 ]
 
 
@@ -413,6 +414,12 @@ def philox4x32_10(ctr, key):
     o = (C.c_uint32 * 4)()
     _lib.rt_philox4x32_10(c, k, o)
     return list(o)
+
+
+def sample_stream(seed, pixel, sample, n):
+    out = (C.c_uint32 * n)()
+    _lib.rt_sample_stream(seed, pixel, sample, out, n)
+    return list(out)
 
 
 def aabb_hit(bmin, bmax, orig, direction, t_min, t_max) -> bool:

@@ -382,6 +382,12 @@ void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
     for (int i = 0; i < 4; ++i) out[i] = p.v[i];
 }
 
+// first n raw words of the stream of one (pixel, sample): known-answer tests
+void rt_sample_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t *out, int n) {
+    Xor128 g = xor128_seed(pixel, sample, (uint32_t)seed, (uint32_t)(seed >> 32));
+    for (int i = 0; i < n; ++i) out[i] = xor128_next(g);
+}
+
 // aabb::hit, gpu-version/aabb.hpp:15-29
 int rt_aabb_hit(const float bmin[3], const float bmax[3], const float orig[3], const float dir[3], float t_min_f,
                 float t_max_f) {

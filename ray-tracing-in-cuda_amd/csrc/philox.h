@@ -1,13 +1,18 @@
 // Philox4x32-10 counter-based RNG (Salmon et al., SC'11), host + device.
 //
 // Replaces the reference's per-pixel curand XORWOW state (48 B/pixel in global
-// memory, gpu-version/main.cu:120-125, 487-496) with a stateless stream:
-//     key     = (seed_lo, seed_hi)
-//     counter = (pixel_id, sample_index, block_index, 0)
-// and draw n of a sample is word n%4 of block n/4.  A uniform is the top 24
-// bits, xi = (word >> 8) * 2^-24 in [0,1), exactly representable in fp32 and
-// fp64, which is what lets the compiled fp64 reference (oracle/_ref) consume
-// the identical stream through its rand() hook.
+// memory, gpu-version/main.cu:120-125, 487-496) with a stream that needs no memory:
+//   * every (pixel, sample) gets its own generator, seeded by ONE counter-based block
+//         Philox4x32-10(counter = (pixel_id, sample_index, 0, 0), key = (seed_lo, seed_hi))
+//     whose four words are the state (x, y, z, w) of
+//   * Marsaglia's xorshift128 ("xor128", 7 integer ops per draw), which yields the
+//     sample's uniforms in sequence.
+// Samples are independent of each other and of the schedule (counter-based seeding);
+// inside a sample the cheap generator avoids one Philox block per four draws, which
+// every inlined call site paid on every iteration because some lane of the wave is
+// always at a block boundary.  A uniform is the top 24 bits, xi = (word >> 8) * 2^-24
+// in [0,1), exactly representable in fp32 and fp64, which is what lets the compiled
+// fp64 reference (oracle/_ref) consume the identical stream through its rand() hook.
 #pragma once
 #include <stdint.h>
 
@@ -55,6 +60,25 @@ RTMI_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
     o.v[2] = c2;
     o.v[3] = c3;
     return o;
+}
+
+struct Xor128 {
+    uint32_t x, y, z, w;
+};
+
+RTMI_HD Xor128 xor128_seed(uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1) {
+    Philox4 p = philox4x32_10(pixel, sample, 0u, 0u, k0, k1);
+    Xor128 g;
+    g.x = p.v[0], g.y = p.v[1], g.z = p.v[2], g.w = p.v[3];
+    if ((g.x | g.y | g.z | g.w) == 0u) g.w = 0x9E3779B9u;  // the all-zero state is a fixed point
+    return g;
+}
+
+RTMI_HD uint32_t xor128_next(Xor128 &g) {  // Marsaglia, "Xorshift RNGs" (2003), xor128
+    const uint32_t t = g.x ^ (g.x << 11);
+    g.x = g.y, g.y = g.z, g.z = g.w;
+    g.w = g.w ^ (g.w >> 19) ^ (t ^ (t >> 8));
+    return g.w;
 }
 
 }  // namespace rtmi

@@ -6,7 +6,7 @@
 //            hittable_list::hit + sphere/rect/cylinder::hit   gpu-version/object.cuh
 //            material::scatter / emitted       gpu-version/material.cuh
 //            camera::get_ray                   cmake-cpu-version/camera.h:32-39
-//            curand XORWOW per-pixel state     -> stateless Philox4x32-10 (philox.h)
+//            curand XORWOW per-pixel state     -> Philox-seeded xorshift128 per (pixel, sample) (philox.h)
 //
 // Shape of the kernel
 //   * 256-thread workgroup = 4 wave64.  A wave owns an 8x8 pixel tile and a range of
@@ -51,82 +51,24 @@ static constexpr float kTMin = 0.001f;  // main.cu:45 / main.cpp:22
 
 // ---------------------------------------------------------------- RNG
 struct LaneRng {
-    uint32_t pixel, sample, block;
-    uint32_t b0, b1, b2, b3;
-    int pos;
+    Xor128 g;
     uint32_t draws;
 };
 
-__device__ __forceinline__ void rng_start(LaneRng &g, uint32_t pixel, uint32_t sample) {
-    g.pixel = pixel;
-    g.sample = sample;
-    g.block = 0;
-    g.pos = 4;
+__device__ __forceinline__ void rng_start(LaneRng &r, uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1) {
+    r.g = xor128_seed(pixel, sample, k0, k1);
 }
 
 template <bool COUNT>
-__device__ __forceinline__ float rng_next(LaneRng &g, uint32_t k0, uint32_t k1) {
-    if (g.pos == 4) {
-        Philox4 p = philox4x32_10(g.pixel, g.sample, g.block, 0u, k0, k1);
-        g.b0 = p.v[0], g.b1 = p.v[1], g.b2 = p.v[2], g.b3 = p.v[3];
-        g.block++;
-        g.pos = 0;
-    }
-    uint32_t w = g.pos == 0 ? g.b0 : (g.pos == 1 ? g.b1 : (g.pos == 2 ? g.b2 : g.b3));
-    g.pos++;
-    if (COUNT) g.draws++;
+__device__ __forceinline__ float rng_next(LaneRng &r) {
+    const uint32_t w = xor128_next(r.g);
+    if (COUNT) r.draws++;
     return (float)(w >> 8) * (1.0f / 16777216.0f);
 }
 
-// Two / three consecutive uniforms with at most ONE block generation: lanes of a wave sit
-// at different stream positions, so every inlined refill site runs whenever any lane is at
-// a block boundary -- i.e. always.  Drawing groups costs one Philox per group, not per draw.
 template <bool COUNT>
-__device__ __forceinline__ void rng_next2(LaneRng &g, uint32_t k0, uint32_t k1, float &u0, float &u1) {
-    const int pos = g.pos;  // 0..4 words already used of the current block
-    uint32_t w0, w1;
-    if (pos <= 2) {
-        w0 = pos == 0 ? g.b0 : (pos == 1 ? g.b1 : g.b2);
-        w1 = pos == 0 ? g.b1 : (pos == 1 ? g.b2 : g.b3);
-        g.pos = pos + 2;
-    } else {
-        const uint32_t last = g.b3;
-        Philox4 p = philox4x32_10(g.pixel, g.sample, g.block, 0u, k0, k1);
-        g.b0 = p.v[0], g.b1 = p.v[1], g.b2 = p.v[2], g.b3 = p.v[3];
-        g.block++;
-        w0 = pos == 3 ? last : g.b0;
-        w1 = pos == 3 ? g.b0 : g.b1;
-        g.pos = pos - 2;
-    }
-    if (COUNT) g.draws += 2;
-    u0 = (float)(w0 >> 8) * (1.0f / 16777216.0f);
-    u1 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
-}
-
-template <bool COUNT>
-__device__ __forceinline__ void rng_next3(LaneRng &g, uint32_t k0, uint32_t k1, float &u0, float &u1, float &u2) {
-    const int pos = g.pos;
-    uint32_t w0, w1, w2;
-    if (pos <= 1) {
-        w0 = pos == 0 ? g.b0 : g.b1;
-        w1 = pos == 0 ? g.b1 : g.b2;
-        w2 = pos == 0 ? g.b2 : g.b3;
-        g.pos = pos + 3;
-    } else {
-        const uint32_t o2 = g.b2, o3 = g.b3;
-        Philox4 p = philox4x32_10(g.pixel, g.sample, g.block, 0u, k0, k1);
-        g.b0 = p.v[0], g.b1 = p.v[1], g.b2 = p.v[2], g.b3 = p.v[3];
-        g.block++;
-        // pos = 2: old b2, old b3, new b0 | pos = 3: old b3, new b0, new b1 | pos = 4: new b0..b2
-        w0 = pos == 2 ? o2 : (pos == 3 ? o3 : g.b0);
-        w1 = pos == 2 ? o3 : (pos == 3 ? g.b0 : g.b1);
-        w2 = pos == 2 ? g.b0 : (pos == 3 ? g.b1 : g.b2);
-        g.pos = pos - 1;
-    }
-    if (COUNT) g.draws += 3;
-    u0 = (float)(w0 >> 8) * (1.0f / 16777216.0f);
-    u1 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
-    u2 = (float)(w2 >> 8) * (1.0f / 16777216.0f);
+__device__ __forceinline__ float rng_pm1(LaneRng &r) {  // random_double(-1, 1): -1 + 2 xi, exact
+    return -1.0f + 2.0f * rng_next<COUNT>(r);
 }
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -222,8 +164,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     int mine = 0;                            // !POOL: samples of the home pixel started so far
 
     LaneRng rng;
-    rng.pixel = 0, rng.sample = 0, rng.block = 0, rng.pos = 4, rng.draws = 0;
-    rng.b0 = rng.b1 = rng.b2 = rng.b3 = 0;
+    rng.g.x = rng.g.y = rng.g.z = 0u, rng.g.w = 1u, rng.draws = 0;
 
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, ra = 1, rinv_a = 1;
     float beta_r = 1, beta_g = 1, beta_b = 1, L_r = 0, L_g = 0, L_b = 0;
@@ -258,17 +199,15 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             }
             if (start) {
                 cur_p = sp;
-                rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss);
-                float ju, jv;
-                rng_next2<COUNT>(rng, k0, k1, ju, jv);
-                float u = ((float)spx + ju) / wm1;
-                float v = ((float)spy + jv) / hm1;
+                rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss, k0, k1);
+                float u = ((float)spx + rng_next<COUNT>(rng)) / wm1;
+                float v = ((float)spy + rng_next<COUNT>(rng)) / hm1;
                 float offx = 0.0f, offy = 0.0f, offz = 0.0f;
                 if (P.flags & RT_FLAG_DEFOCUS_BLUR) {
                     float px, py;
                     do {  // random_in_unit_disk, vec3.h:157-165
-                        rng_next2<COUNT>(rng, k0, k1, px, py);
-                        px = -1.0f + 2.0f * px, py = -1.0f + 2.0f * py;
+                        px = rng_pm1<COUNT>(rng);
+                        py = rng_pm1<COUNT>(rng);
                     } while (fmaf(px, px, py * py) >= 1.0f);
                     float rdx = P.cam.lens_radius * px, rdy = P.cam.lens_radius * py;
                     offx = fmaf(P.cam.u[0], rdx, P.cam.v[0] * rdy);
@@ -553,8 +492,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 float sx = 0, sy = 0, sz = 0, sl2 = 1;
                 if (kind <= MK_METAL) {
                     do {
-                        rng_next3<COUNT>(rng, k0, k1, sx, sy, sz);
-                        sx = -1.0f + 2.0f * sx, sy = -1.0f + 2.0f * sy, sz = -1.0f + 2.0f * sz;
+                        sx = rng_pm1<COUNT>(rng);
+                        sy = rng_pm1<COUNT>(rng);
+                        sz = rng_pm1<COUNT>(rng);
                         sl2 = dot3(sx, sy, sz, sx, sy, sz);
                     } while (sl2 >= 1.0f);
                 }
@@ -590,7 +530,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         const float xx = 1.0f - cos_t;
                         const float x2 = xx * xx;
                         const float x5 = (x2 * x2) * xx;
-                        refl = fmaf(1.0f - r0, x5, r0) > rng_next<COUNT>(rng, k0, k1);
+                        refl = fmaf(1.0f - r0, x5, r0) > rng_next<COUNT>(rng);
                     }
                     if (refl) {  // reflect(), vec3.h:144-147
                         const float k2 = 2.0f * udn;

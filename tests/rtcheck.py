@@ -69,6 +69,8 @@ def oracle_lib():
         lib.rto_derive_camera.argtypes = [C.POINTER(_RtoCameraParams), C.POINTER(_RtoCamera)]
         lib.rto_philox4x32_10.restype = None
         lib.rto_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        lib.rto_sample_stream.restype = None
+        lib.rto_sample_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int]
         lib.rto_aabb_hit.restype = C.c_int
         lib.rto_aabb_hit.argtypes = [C.POINTER(C.c_float)] * 4 + [C.c_float, C.c_float]
         lib.rto_quantize.restype = C.c_int

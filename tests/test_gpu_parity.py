@@ -269,20 +269,24 @@ def test_full_frame_properties(rtmi, rtcheck):
 
 
 def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
-    """Regression: AABB cluster culling vs the linear scan on the full frame.  Pixel (90, 828),
-    sample 7 of this seed is a path that leaks ~2000 units inside the radius-1000 ground sphere,
-    where the fp32 sphere test (|oc|^2 ~ 4e6, ulp 0.25 >> r^2 = 0.04) reports a noise hit that a
-    fixed-margin box test would skip; the per-lane margin 4e-3 (max|o_i| + extent + 1) keeps the
-    culled kernel bit-identical to the linear one and to the CPU checker."""
-    sc = rtmi.Scene.rtiow(7, 1920, 1080, 16, 50)
+    """AABB cluster culling vs the linear scan on the full frame, bit for bit.  Some paths leak
+    ~2000 units inside the radius-1000 ground sphere, where the fp32 sphere test (|oc|^2 ~ 4e6,
+    ulp 0.25 >> r^2 = 0.04) reports noise hits on small spheres; a fixed-margin box test skipped
+    such a hit once in 33 M samples (found with an earlier random stream: pixel (90, 828)).  The
+    per-lane margin 4e-3 (max|o_i| + extent + 1) keeps the culled kernel identical to the linear
+    one and to the CPU checker."""
+    sc = rtmi.Scene.rtiow(7, 1920, 1080, 24, 50)
     culled = sc.render(rtmi.Opts(seed=SEED))
     linear = sc.render(rtmi.Opts(seed=SEED, variant=16))
     assert np.array_equal(culled, linear)
-    ref, _ = rtcheck.oracle_render(rtcheck.OracleScene(sc), seed=SEED, rows=(828, 829))
-    assert np.array_equal(culled[828], ref[828])
-    one = sc.render(rtmi.Opts(seed=SEED, sample_first=7, sample_count=1, tile_rows=1, tile_first=828, tile_stride=1 << 20))
-    rgb, queries = rtcheck.oracle_sample(sc, SEED, 90, 828, 7)
-    assert queries == 15 and np.allclose(one[0, 90], rgb, rtol=0, atol=2.0 ** -32)
+    osc = rtcheck.OracleScene(sc)
+    for y in (5, 828):
+        ref, _ = rtcheck.oracle_render(osc, seed=SEED, rows=(y, y + 1))
+        assert np.array_equal(culled[y], ref[y])
     st = sc.count(rtmi.Opts(seed=SEED))
     # the culled kernel really skips work: far fewer clusters visited than waves x clusters
-    assert 0 < st.clusters_visited < 0.35 * (st.queries / 64) * 60
+    assert 0 < st.clusters_visited < 0.35 * st.wave_queries * st.cull_clusters
+    assert st.cull_prefix == 8 and st.cull_cluster_size == 8 and st.cull_clusters == 60
+    # a second scene seed and the mixed scene (few spheres: everything sits in the prefix)
+    sc2 = rtmi.Scene.rtiow(11, 960, 540, 16, 50)
+    assert np.array_equal(sc2.render(rtmi.Opts(seed=3)), sc2.render(rtmi.Opts(seed=3, variant=16)))

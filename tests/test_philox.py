@@ -1,5 +1,6 @@
-"""Philox4x32-10 known-answer tests (Random123 kat_vectors) for the product's generator and
-the checker's independent implementation."""
+"""Known-answer tests of the random stream: Philox4x32-10 (Random123 kat_vectors), which seeds every
+(pixel, sample), and xorshift128 (Marsaglia 2003, xor128), which produces the sample's draws --
+for the product's generator and the checker's independent implementation."""
 import ctypes as C
 
 KAT = [
@@ -33,3 +34,33 @@ def test_product_and_checker_agree_on_random_counters(rtmi, rtcheck):
         out = (C.c_uint32 * 4)()
         lib.rto_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
         assert list(out) == rtmi.philox4x32_10(ctr, key)
+
+
+def _xor128_python(x, y, z, w, n):
+    out = []
+    for _ in range(n):
+        t = (x ^ (x << 11)) & 0xFFFFFFFF
+        x, y, z = y, z, w
+        w = (w ^ (w >> 19) ^ (t ^ (t >> 8))) & 0xFFFFFFFF
+        out.append(w)
+    return out
+
+
+def test_xor128_known_answer():
+    # the sequence printed in Marsaglia's paper for the default seed
+    assert _xor128_python(123456789, 362436069, 521288629, 88675123, 5) == [
+        3701687786, 458299110, 2500872618, 3633119408, 516391518]
+
+
+def test_sample_stream_is_philox_seeded_xor128(rtmi, rtcheck):
+    lib = rtcheck.oracle_lib()
+    for seed, pixel, sample in ((2023, 0, 0), (2023, 123456, 7), ((5 << 32) | 9, 2073599, 1023), (0, 0, 0)):
+        state = rtmi.philox4x32_10([pixel, sample, 0, 0], [seed & 0xFFFFFFFF, seed >> 32])
+        want = _xor128_python(*state, 64)
+        assert rtmi.sample_stream(seed, pixel, sample, 64) == want
+        out = (C.c_uint32 * 64)()
+        lib.rto_sample_stream(seed, pixel, sample, out, 64)
+        assert list(out) == want
+    # streams of neighbouring pixels / samples are unrelated
+    a = rtmi.sample_stream(1, 10, 3, 8)
+    assert a != rtmi.sample_stream(1, 11, 3, 8) and a != rtmi.sample_stream(1, 10, 4, 8) and a != rtmi.sample_stream(2, 10, 3, 8)
