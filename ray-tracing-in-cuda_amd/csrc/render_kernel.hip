@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             }
             if (CULL) {
                 // clusters: aabb::hit (aabb.hpp:15-29) for every live lane, then one wave-wide vote
-                const float idx = 1.0f / dx, idy = 1.0f / dy, idz = 1.0f / dz;
+                // 1-ulp reciprocals are enough here: the box test only has to be conservative, and the
+                // margin below is five orders of magnitude larger than their error
+                const float idx = __builtin_amdgcn_rcpf(dx), idy = __builtin_amdgcn_rcpf(dy), idz = __builtin_amdgcn_rcpf(dz);
                 // per-lane box margin covering the fp32 error of the sphere test at this origin's
                 // distance (derivation in render_host.hip): two shifted origins, nothing per box
                 const float marg = 4e-3f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + P.cull_extent1);
@@ -318,11 +320,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     const float lx = (bmn.x - oxm) * idx, ux = (bmx.x - oxp) * idx;
                     const float ly = (bmn.y - oym) * idy, uy = (bmx.y - oyp) * idy;
                     const float lz = (bmn.z - ozm) * idz, uz = (bmx.z - ozp) * idz;
-                    const float tn = fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), fminf(lz, uz));
-                    const float tf = fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), fmaxf(lz, uz));
-                    // dead: (grown) box missed, behind the origin, or entirely beyond the current best
-                    // hit (1e-4 relative slack on top of the margin).  NaN -> live.
-                    return !(tn > tf) && !(tf < 0.0f) && !(tn > best_t * 1.0001f);
+                    // live  <=>  tn <= tf, tf >= 0, tn <= best_t (1 + 1e-4)
+                    //       <=>  max(tn, 0) <= min(tf, best_t (1 + 1e-4))          (NaN -> live)
+                    const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
+                    const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), best_t * 1.0001f), fmaxf(lz, uz));
+                    return !(tn > tf);
                 };
                 for (int g = 0; g < P.ngr; ++g) {
                 if (__builtin_amdgcn_ballot_w64(slab_live(gbox[2 * g], gbox[2 * g + 1])) == 0ull) continue;
@@ -428,6 +430,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
             // ---- shade the winner (ray_color body, main.cu:45-65 / main.cpp:22-38)
             bool path_done = false;
+            // 1/|d| once per query (metal, dielectric and the sky all normalise the direction)
+            const float inv_len = 1.0f / sqrtf(ra);
             if (best_id >= 0) {
                 // hit record of the winner only (the reference fills one per candidate)
                 float px, py, pz, nx, ny, nz;
@@ -510,8 +514,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     const bool odd = kind == MK_LAMBERT_CHECKER && checker_odd(px, py, pz);
                     at_r = odd ? q2.x : q1.x, at_g = odd ? q2.y : q1.y, at_b = odd ? q2.z : q1.z;
                 } else if (kind == MK_METAL) {  // metal::scatter, material.h:47-53
-                    const float inv = 1.0f / sqrtf(ra);
-                    const float ux = inv * dx, uy = inv * dy, uz = inv * dz;
+                    const float ux = inv_len * dx, uy = inv_len * dy, uz = inv_len * dz;
                     const float k2 = 2.0f * dot3(ux, uy, uz, nx, ny, nz);
                     const float rx = fmaf(-k2, nx, ux), ry = fmaf(-k2, ny, uy), rz = fmaf(-k2, nz, uz);
                     ndx = fmaf(q0.y, sx, rx), ndy = fmaf(q0.y, sy, ry), ndz = fmaf(q0.y, sz, rz);
@@ -519,8 +522,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     scattered = dot3(ndx, ndy, ndz, nx, ny, nz) > 0.0f;
                 } else if (kind == MK_DIELECTRIC) {  // dielectric::scatter, material.h:66-95
                     const float ratio = front ? q0.z : q0.y;
-                    const float inv = 1.0f / sqrtf(ra);
-                    const float ux = inv * dx, uy = inv * dy, uz = inv * dz;
+                    const float ux = inv_len * dx, uy = inv_len * dy, uz = inv_len * dz;
                     const float udn = dot3(ux, uy, uz, nx, ny, nz);
                     const float cos_t = fminf(-udn, 1.0f);
                     const float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
@@ -567,8 +569,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 // miss: main.cpp:36-38 (sky) or main.cu:63 (constant background)
                 float bg_r, bg_g, bg_b;
                 if (P.flags & RT_FLAG_SKY_GRADIENT) {
-                    const float inv = 1.0f / sqrtf(ra);
-                    const float t = 0.5f * (inv * dy + 1.0f);
+                    const float t = 0.5f * (inv_len * dy + 1.0f);
                     const float omt = 1.0f - t;
                     bg_r = fmaf(t, 0.5f, omt), bg_g = fmaf(t, 0.7f, omt), bg_b = fmaf(t, 1.0f, omt);
                 } else {
