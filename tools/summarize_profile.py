@@ -18,7 +18,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         for r in csv.DictReader(open(f)):
             if "render_kernel" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); launches[r["Counter_Name"]] += 1
-out["pmc_workload"] = "bench.py --steps 1 --warmup 0 --spp 256 (RTIOW 1920x1080, one render_kernel launch per pass)"
+out["pmc_workload"] = "bench.py --steps 1 --warmup 0 (the bench workload: RTIOW 1920x1080x1024, one render_kernel launch per pass)"
 out["pmc"] = {k: agg[k] / max(1, launches[k]) for k in sorted(agg)}
 p = out["pmc"]
 d = {}
@@ -37,5 +37,10 @@ if "WRITE_SIZE" in p: d["hbm_write_bytes_per_launch"] = p["WRITE_SIZE"] * 1024
 out["derived"] = d
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json"), "w"), indent=1)
+if "hbm_read_bytes_per_launch" in d and "hbm_write_bytes_per_launch" in d:
+    tf = {"1920x1080x1024": {"bytes_per_launch": int(d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]),
+                             "read_bytes": int(d["hbm_read_bytes_per_launch"]), "write_bytes": int(d["hbm_write_bytes_per_launch"]),
+                             "source": f"profiles/{tag}_rocprof_summary.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE, separate passes, render_kernel only"}}
+    json.dump(tf, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out["derived"], indent=1)); print(out.get("render_dispatch")); 
 for k in out["kernel_stats"][:4]: print(k["Name"][:70], k["Calls"], k["AverageNs"])
