@@ -169,6 +169,17 @@ int rt_scene_add_cylinder(rt_scene *s, float radius, float zmin, float zmax, int
                           const float rot_axis[3], float rot_degrees, const float translate[3]);
 /* negative ids above = -rt_status */
 
+/* ---- animation (gpu-version/blue.py, blue2.py, dna.py: the frame harness) ----- */
+/* blue.py:16-19 / blue2.py:16-19: add `degrees` to rotate.angle of every cylinder that has a
+ * "rotate" and rebuild its transform; returns the number of cylinders changed (or -rt_status). */
+int rt_scene_rotate_cylinders(rt_scene *s, double degrees);
+int rt_scene_set_output_file(rt_scene *s, const char *path);
+/* dna.py:17-98: the DNA frame at `angle_degrees` -- 60 emissive spheres + 30 emissive rotated
+ * cylinders (3 helices x 10 rungs) placed into a copy of `base` (camera, background, size: the
+ * reference uses basic_scene.json); base == NULL uses that file's values. */
+rt_scene *rt_scene_dna(const rt_scene *base, double angle_degrees);
+rt_scene *rt_scene_clone(const rt_scene *s);
+
 /* CLI overrides -w -h -spp -d (cmake-cpu-version/main.cpp:71-81); <= 0 keeps the
  * value. Re-derives the camera when the aspect changes. */
 int rt_scene_override(rt_scene *s, int width, int height, int spp, int max_depth);
@@ -259,6 +270,12 @@ int rt_write_ppm(const char *path, const float *rgb_sum, int width, int height, 
  * to bottom; gamma = 0 gives write_image()'s linear bytes (color.cuh:15-35). */
 int rt_quantize_rgb8(const float *rgb_sum, int width, int height, int spp, int gamma,
                      uint8_t *out);
+
+/* write_image(), gpu-version/color.cuh:15-35 (called at main.cu:514 with json["output_file"]):
+ * 8-bit RGB PNG, rows top to bottom; gamma = 0 is the reference's linear image. */
+int rt_write_png(const char *path, const float *rgb_sum, int width, int height, int spp, int gamma);
+/* the scene's "output_file" (parser.hpp:566-567, default "main.png") */
+const char *rt_scene_output_file(const rt_scene *s);
 
 /* ---- misc -------------------------------------------------------------- */
 const char *rt_last_error(void);

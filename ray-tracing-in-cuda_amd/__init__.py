@@ -144,6 +144,10 @@ _sig("rt_scene_add_sphere", C.c_int, _p, _f3, C.c_float, C.c_int)
 _sig("rt_scene_add_rect", C.c_int, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int)
 _sig("rt_scene_add_cylinder", C.c_int, _p, C.c_float, C.c_float, C.c_float, C.c_int, _f3, C.c_float, _f3)
 _sig("rt_scene_override", C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("rt_scene_rotate_cylinders", C.c_int, _p, C.c_double)
+_sig("rt_scene_set_output_file", C.c_int, _p, C.c_char_p)
+_sig("rt_scene_dna", _p, _p, C.c_double)
+_sig("rt_scene_clone", _p, _p)
 _sig("rt_scene_get_info", C.c_int, _p, C.POINTER(_Info))
 _sig("rt_scene_get_camera", C.c_int, _p, C.POINTER(_Camera))
 _sig("rt_scene_get_prims", C.c_int, _p, _p, C.c_int)
@@ -157,6 +161,8 @@ _sig("rt_render_hip_count", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
 _sig("rt_shard_scatter_rows", C.c_int, _p, C.POINTER(Opts), _p, _p)
 _sig("rt_write_ppm", C.c_int, C.c_char_p, _p, C.c_int, C.c_int, C.c_int)
 _sig("rt_quantize_rgb8", C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p)
+_sig("rt_write_png", C.c_int, C.c_char_p, _p, C.c_int, C.c_int, C.c_int, C.c_int)
+_sig("rt_scene_output_file", C.c_char_p, _p)
 _sig("rt_philox4x32_10", None, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
 _sig("rt_aabb_hit", C.c_int, _f3, _f3, _f3, _f3, C.c_float, C.c_float)
 _sig("rt_sample_stream", None, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int)
@@ -170,7 +176,8 @@ C_SYMBOLS = [
     "rt_scene_override", "rt_scene_get_info", "rt_scene_get_camera", "rt_scene_get_prims",
     "rt_scene_get_materials", "rt_scene_get_textures", "rt_shard_rows", "rt_shard_global_row",
     "rt_render_hip_device", "rt_render_hip", "rt_render_hip_count", "rt_shard_scatter_rows", "rt_write_ppm",
-    "rt_quantize_rgb8", "rt_philox4x32_10", "rt_aabb_hit", "rt_sample_stream",
+    "rt_quantize_rgb8", "rt_philox4x32_10", "rt_aabb_hit", "rt_sample_stream", "rt_write_png",
+    "rt_scene_output_file", "rt_scene_rotate_cylinders", "rt_scene_set_output_file", "rt_scene_dna", "rt_scene_clone",
 ]
 
 
@@ -280,6 +287,24 @@ class Scene:
         off = _v3(translate) if translate is not None else None
         return _check_id(_lib.rt_scene_add_cylinder(self._h, radius, zmin, zmax, material, axis, deg, off), "cylinder")
 
+    # ---- animation (blue.py / blue2.py / dna.py) ---------------------------------------------
+    def rotate_cylinders(self, degrees: float) -> int:
+        return _check_id(_lib.rt_scene_rotate_cylinders(self._h, degrees), "rotate_cylinders")
+
+    def set_output_file(self, path: str):
+        _check(_lib.rt_scene_set_output_file(self._h, os.fsencode(path)), "set_output_file")
+
+    def clone(self) -> "Scene":
+        return Scene(_lib.rt_scene_clone(self._h))
+
+    @classmethod
+    def dna(cls, angle_degrees: float, base: "Scene | None" = None) -> "Scene":
+        """dna.py:17-98: the DNA animation frame at this angle over `base` (default: basic_scene.json)."""
+        h = _lib.rt_scene_dna(base._h if base is not None else None, angle_degrees)
+        if not h:
+            raise RtmiError(_guess_status(), "rt_scene_dna")
+        return cls(h)
+
     def override(self, width=0, height=0, spp=0, max_depth=0):
         _check(_lib.rt_scene_override(self._h, width, height, spp, max_depth), "override")
 
@@ -326,6 +351,10 @@ class Scene:
 
     def textures(self) -> np.ndarray:
         return self._table(_lib.rt_scene_get_textures, TEXTURE_DTYPE)
+
+    @property
+    def output_file(self) -> str:
+        return _lib.rt_scene_output_file(self._h).decode()
 
     def to_json(self) -> str:
         n = _lib.rt_scene_to_json(self._h, None, 0)
@@ -397,6 +426,14 @@ def output_image(image: np.ndarray, samples_per_pixel: int, filename: str = "mai
     h, w = img.shape[0], img.shape[1]
     _check(_lib.rt_write_ppm(os.fsencode(filename), img.ctypes.data_as(C.c_void_p), w, h, samples_per_pixel),
            "rt_write_ppm")
+
+
+def write_image(image: np.ndarray, samples_per_pixel: int, filename: str = "main.png", gamma: bool = False):
+    """gpu-version/color.cuh:15-35 ``write_image``: 8-bit RGB PNG of the linear means."""
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    h, w = img.shape[0], img.shape[1]
+    _check(_lib.rt_write_png(os.fsencode(filename), img.ctypes.data_as(C.c_void_p), w, h, samples_per_pixel, int(gamma)),
+           "rt_write_png")
 
 
 def quantize_rgb8(image: np.ndarray, samples_per_pixel: int, gamma: bool = True) -> np.ndarray:

@@ -259,6 +259,117 @@ int rt_scene_add_cylinder(rt_scene *s, float radius, float zmin, float zmax, int
                         translate ? off : nullptr);
 }
 
+// ---- animation ---------------------------------------------------------------------------
+rt_scene *rt_scene_clone(const rt_scene *src) {
+    if (bad_scene(src, "rt_scene_clone")) return nullptr;
+    rt_scene *s = new (std::nothrow) rt_scene();
+    if (!s) {
+        set_error("out of memory");
+        return nullptr;
+    }
+    s->s = src->s;
+    s->s.dev.reset();  // device residency is per scene object
+    s->s.touch();
+    return s;
+}
+
+int rt_scene_set_output_file(rt_scene *s, const char *path) {
+    if (bad_scene(s, "rt_scene_set_output_file") || !path) return RT_ERR_ARG;
+    s->s.output_file = path;
+    return RT_OK;
+}
+
+int rt_scene_rotate_cylinders(rt_scene *s, double degrees) {
+    if (bad_scene(s, "rt_scene_rotate_cylinders")) return -RT_ERR_ARG;
+    Scene &sc = s->s;
+    int changed = 0;
+    for (size_t i = 0; i < sc.prims.size(); ++i) {
+        if (sc.prims[i].type != RT_PRIM_CYLINDER || !sc.xforms[i].has_rotate) continue;
+        CylinderXform xf = sc.xforms[i];
+        xf.degrees += degrees;
+        // rebuild through the same path the parser uses (parser.hpp:423-440)
+        Scene tmp;
+        tmp.mats.resize(sc.mats.size());
+        int rc = add_cylinder(tmp, sc.prims[i].f[0], sc.prims[i].f[1], sc.prims[i].f[2], sc.prims[i].material, xf.axis,
+                              xf.degrees, xf.has_translate ? xf.offset : nullptr);
+        if (rc < 0) return rc;
+        sc.prims[i] = tmp.prims[0];
+        sc.xforms[i] = tmp.xforms[0];
+        ++changed;
+    }
+    sc.touch();
+    return changed;
+}
+
+rt_scene *rt_scene_dna(const rt_scene *base, double angle) {
+    rt_scene *s = new (std::nothrow) rt_scene();
+    if (!s) {
+        set_error("out of memory");
+        return nullptr;
+    }
+    Scene &sc = s->s;
+    if (base) {
+        sc = base->s;
+        sc.dev.reset();
+        sc.prims.clear(), sc.xforms.clear(), sc.mats.clear(), sc.texs.clear();
+    } else {  // gpu-version/basic_scene.json
+        sc.width = 1600, sc.height = 900, sc.spp = 100, sc.max_depth = 50;
+        sc.background[0] = 0.0005f, sc.background[1] = 0.0007f, sc.background[2] = 0.00099f;
+        sc.flags = RT_FLAG_DEFOCUS_BLUR;
+        sc.cam = CameraParams();
+        sc.cam.lookfrom[0] = 0, sc.cam.lookfrom[1] = 0, sc.cam.lookfrom[2] = -20;
+        sc.cam.vfov = 23, sc.cam.aperture = 0.1;
+    }
+    const double pi = std::acos(-1.0);
+    const int num_object = 5;
+    const double space = 5;
+    // dna.py:29-53: three solid colours and three diffuse_light materials per i in range(-15, 15)
+    for (int i = 0; i < num_object * 6; ++i) {
+        const double cols[3][3] = {{232 / 256.0, 209 / 256.0, 209 / 256.0},
+                                   {232 / 256.0, 209 / 256.0, 209 / 256.0},
+                                   {202 / 256.0, 202 / 256.0, 224 / 256.0}};
+        for (int k = 0; k < 3; ++k) {
+            rt_texture t;
+            memset(&t, 0, sizeof t);
+            t.type = RT_TEX_SOLID;
+            for (int c = 0; c < 3; ++c) t.c0[c] = t.c1[c] = (float)cols[k][c];
+            sc.texs.push_back(t);
+        }
+        for (int k = 0; k < 3; ++k) {
+            rt_material m;
+            memset(&m, 0, sizeof m);
+            m.type = RT_MAT_DIFFUSE_LIGHT;
+            m.texture = i * 3 + k;
+            sc.mats.push_back(m);
+        }
+    }
+    // dna.py:55-84
+    for (int offset = 0; offset < 3; ++offset) {
+        for (int i = 0; i < 2 * num_object; ++i) {
+            const int id = i - num_object;
+            const double theta = (36.0 * (id + num_object) + angle) / 180.0 * pi;
+            const double xoffset = offset * space - space;
+            const double zoffset = std::fabs(offset - 1.0) * -20 + 20;
+            auto add_sphere = [&](double th, int mat) {
+                rt_prim p;
+                memset(&p, 0, sizeof p);
+                p.type = RT_PRIM_SPHERE, p.material = mat;
+                p.f[0] = (float)(2.5 * std::cos(th) + xoffset), p.f[1] = (float)id;
+                p.f[2] = (float)(2.5 * std::sin(th) + zoffset), p.f[3] = 0.5f;
+                sc.prims.push_back(p);
+                sc.xforms.emplace_back();
+            };
+            add_sphere(theta, i * 3 + 0);
+            add_sphere(theta + pi, i * 3 + 1);
+            const double axis[3] = {0, 1, 0}, off[3] = {xoffset, (double)id, zoffset};
+            int rc = add_cylinder(sc, 0.3f, -2.18f, 2.18f, i * 3 + 2, axis, 36.0 * -(id + num_object) + 90 + angle, off);
+            if (rc < 0) return finish(s, RT_ERR_SCENE);
+        }
+    }
+    sc.touch();
+    return finish(s, scene_validate(sc));
+}
+
 int rt_scene_override(rt_scene *s, int width, int height, int spp, int max_depth) {
     if (bad_scene(s, "rt_scene_override")) return RT_ERR_ARG;
     int w = s->s.width, h = s->s.height, p = s->s.spp, d = s->s.max_depth;
@@ -312,6 +423,8 @@ int rt_scene_get_textures(const rt_scene *s, rt_texture *out, int cap) {
         for (int i = 0; i < n && i < cap; ++i) out[i] = s->s.texs[i];
     return n;
 }
+
+const char *rt_scene_output_file(const rt_scene *s) { return s ? s->s.output_file.c_str() : ""; }
 
 // ---- output -------------------------------------------------------------------------
 // write_color(FILE*, color, spp), gpu-version/color.cuh:70-95: fp32 throughout
@@ -371,6 +484,84 @@ int rt_write_ppm(const char *path, const float *rgb_sum, int width, int height, 
     }
     if (fclose(fp) != 0) {
         set_error("error closing '%s'", path);
+        return RT_ERR_IO;
+    }
+    return RT_OK;
+}
+
+// write_image(), gpu-version/color.cuh:15-35: 8-bit RGB PNG of the LINEAR means (no gamma), rows top
+// to bottom.  The reference encodes with stb_image_write; here a minimal encoder (zlib "stored"
+// blocks, no compression) keeps the library dependency-free.  gamma != 0 applies write_color's sqrt.
+namespace {
+uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::string &o, uint32_t v) {
+    o.push_back((char)(v >> 24)), o.push_back((char)(v >> 16)), o.push_back((char)(v >> 8)), o.push_back((char)v);
+}
+void put_chunk(std::string &png, const char type[4], const std::string &data) {
+    put_be32(png, (uint32_t)data.size());
+    std::string body(type, 4);
+    body += data;
+    png += body;
+    put_be32(png, crc32_update(0xFFFFFFFFu, (const uint8_t *)body.data(), body.size()) ^ 0xFFFFFFFFu);
+}
+}  // namespace
+
+int rt_write_png(const char *path, const float *rgb_sum, int width, int height, int spp, int gamma) {
+    if (!path || !rgb_sum || width <= 0 || height <= 0 || spp <= 0) {
+        set_error("rt_write_png: bad argument");
+        return RT_ERR_ARG;
+    }
+    // raw scanlines: filter byte 0 + RGB bytes, top row first
+    std::string raw;
+    raw.reserve((size_t)height * ((size_t)width * 3 + 1));
+    for (int j = height - 1; j >= 0; --j) {
+        raw.push_back(0);
+        for (int i = 0; i < width; ++i)
+            for (int c = 0; c < 3; ++c) raw.push_back((char)quantize(rgb_sum[((size_t)j * width + i) * 3 + c], spp, gamma));
+    }
+    std::string z;
+    z.push_back(0x78), z.push_back(0x01);  // zlib header, no preset dictionary
+    uint32_t a = 1, b = 0;                 // adler32
+    for (unsigned char ch : raw) a = (a + ch) % 65521u, b = (b + a) % 65521u;
+    size_t pos = 0;
+    do {
+        size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
+        z.push_back(pos + n == raw.size() ? 1 : 0);  // BFINAL, BTYPE = 00 (stored)
+        z.push_back((char)(n & 0xFF)), z.push_back((char)(n >> 8));
+        z.push_back((char)(~n & 0xFF)), z.push_back((char)((~n >> 8) & 0xFF));
+        z.append(raw, pos, n);
+        pos += n;
+    } while (pos < raw.size());
+    put_be32(z, (b << 16) | a);
+    std::string png("\x89PNG\r\n\x1a\n", 8);
+    std::string ihdr;
+    put_be32(ihdr, (uint32_t)width), put_be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8), ihdr.push_back(2), ihdr.push_back(0), ihdr.push_back(0), ihdr.push_back(0);  // 8-bit RGB
+    put_chunk(png, "IHDR", ihdr);
+    put_chunk(png, "IDAT", z);
+    put_chunk(png, "IEND", std::string());
+    FILE *fp = fopen(path, "wb");
+    if (!fp) {
+        set_error("cannot open '%s' for writing", path);
+        return RT_ERR_IO;
+    }
+    bool ok = fwrite(png.data(), 1, png.size(), fp) == png.size();
+    ok = (fclose(fp) == 0) && ok;
+    if (!ok) {
+        set_error("short write to '%s'", path);
         return RT_ERR_IO;
     }
     return RT_OK;

@@ -23,7 +23,7 @@ static double now_s() {
 static int usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [-f scene.json | --rtiow] [-w W] [-h H] [-d DEPTH] [-spp N] [-o out.ppm]\n"
-            "          [--seed S] [--scene-seed S] [--device N] [--chunk N] [--dump-json file] [--count]\n",
+            "          [--seed S] [--scene-seed S] [--device N] [--chunk N] [--dump-json file] [--count] [--no-png]\n",
             argv0);
     return 2;
 }
@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
     std::string scene_file = "sample_scene.json";  // main.cu:456 default
     std::string out_file = "main.ppm";             // main.cu:512
     std::string dump_json;
-    bool rtiow = false, have_file = false, count = false;
+    bool rtiow = false, have_file = false, count = false, no_png = false;
     int w = 0, h = 0, depth = 0, spp = 0, device = 0, chunk = 0;
     unsigned long long seed = 2023;
     unsigned scene_seed = 7;  // srand(7), main.cpp:119
@@ -57,6 +57,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--dump-json")) dump_json = need("--dump-json");
         else if (!strcmp(argv[i], "--rtiow")) rtiow = true;
         else if (!strcmp(argv[i], "--count")) count = true;
+        else if (!strcmp(argv[i], "--no-png")) no_png = true;
         else if (!strcmp(argv[i], "--help")) return usage(argv[0]);
         else {
             fprintf(stderr, "unknown argument '%s'\n", argv[i]);
@@ -115,6 +116,13 @@ int main(int argc, char **argv) {
     if (rt_write_ppm(out_file.c_str(), img.data(), info.width, info.height, info.samples_per_pixel) != RT_OK) {
         fprintf(stderr, "rtmi: %s\n", rt_last_error());
         return 1;
+    }
+    // write_image(..., data["output_file"]), main.cu:514: linear PNG next to the PPM (skipped when the
+    // directory of output_file does not exist, which the reference would crash on)
+    if (!no_png) {
+        const char *png = rt_scene_output_file(sc);
+        if (rt_write_png(png, img.data(), info.width, info.height, info.samples_per_pixel, 0) != RT_OK)
+            fprintf(stderr, "rtmi: PNG not written: %s\n", rt_last_error());
     }
     fprintf(stderr, "Program finish, cost: %f s\n", now_s() - t0);  // main.cu:519-520
     rt_scene_free(sc);

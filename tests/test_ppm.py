@@ -49,3 +49,30 @@ def test_linear_png_bytes(rtmi, rtcheck):
     assert list(out) == [128, 255, 64]
     lib = rtcheck.oracle_lib()
     assert [lib.rto_quantize(float(v), 8, 0) for v in img[0, 0]] == [128, 255, 64]
+
+
+def test_png_writer_round_trip(rtmi, tmp_path):
+    """rt_write_png: a valid PNG (signature, IHDR, zlib stream, CRCs) holding write_image's bytes."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 3, (37, 301, 3)).astype(np.float32) * 5  # > 65535 raw bytes: several stored blocks
+    path = str(tmp_path / "o.png")
+    rtmi.write_image(img, 5, path)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + body) == crc
+        chunks.append((typ, body))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[0][1][:10])
+    assert (w, h, depth, ctype) == (301, 37, 8, 2)
+    raw = zlib.decompress(chunks[1][1])
+    rows = np.frombuffer(raw, dtype=np.uint8).reshape(37, 1 + 301 * 3)
+    assert not rows[:, 0].any()
+    np.testing.assert_array_equal(rows[:, 1:].reshape(37, 301, 3), rtmi.quantize_rgb8(img, 5, gamma=False))
