@@ -45,7 +45,7 @@ def gather_framebuffer(local: torch.Tensor, scene, base: Opts, rank: int, world:
     if world == 1:
         full = out if out is not None else torch.empty((scene.height, scene.width, 3), dtype=local.dtype,
                                                        device=local.device)
-        rows = torch.as_tensor(scene.shard_global_rows(shard_opts(base, 0, 1)), device=local.device)
+        rows = _rows_on(scene, base, 0, 1, local.device)
         full.index_copy_(0, rows, local[: len(rows)])
         return full
     parts = None
@@ -60,10 +60,23 @@ def gather_framebuffer(local: torch.Tensor, scene, base: Opts, rank: int, world:
     full = out if out is not None else torch.empty((scene.height, scene.width, 3), dtype=local.dtype,
                                                    device=local.device)
     for r in range(world):
-        rows = scene.shard_global_rows(shard_opts(base, r, world))
+        rows = _rows_on(scene, base, r, world, local.device)
         if len(rows):
-            full.index_copy_(0, torch.as_tensor(rows, device=local.device), parts[r][: len(rows)])
+            full.index_copy_(0, rows, parts[r][: len(rows)])
     return full
+
+
+_ROWS_CACHE: dict = {}
+
+
+def _rows_on(scene, base: Opts, r: int, world: int, device) -> torch.Tensor:
+    """Global row indices of rank r's shard as a tensor on `device` (cached: the gather runs every step)."""
+    key = (id(scene), scene.height, base.tile_rows, r, world, str(device))
+    t = _ROWS_CACHE.get(key)
+    if t is None:
+        t = torch.as_tensor(scene.shard_global_rows(shard_opts(base, r, world)), device=device)
+        _ROWS_CACHE[key] = t
+    return t
 
 
 def shard_row_table(scene, base: Opts, world: int) -> list[np.ndarray]:
