@@ -9,8 +9,9 @@
 //            curand XORWOW per-pixel state     -> Philox-seeded xorshift128 per (pixel, sample) (philox.h)
 //
 // Shape of the kernel
-//   * 256-thread workgroup = 4 wave64.  A wave owns an 8x8 pixel tile and a range of
-//     sample indices; a work-item (lane) owns ONE PATH at a time and runs its whole
+//   * 256-thread workgroup = 4 wave64; the grid only fills the chip (persistent waves) and
+//     every wave pulls work items -- an 8x8 pixel tile x 64 sample indices -- from one
+//     global counter.  A work-item (lane) owns ONE PATH at a time and runs its whole
 //     bounce loop (get_color), exactly as the reference's thread does for its pixel.
 //   * lanes stay converged across bounces: every iteration of the main loop is one
 //     closest-hit query for all live lanes over a wave-uniform primitive loop.  A lane
@@ -29,6 +30,11 @@
 //     record (broadcast ds_read_b128), four spheres are fetched one batch ahead of use.
 //     No virtual calls, no pointer chasing; cold data (1/r, material records) stays in
 //     global memory / L2 and is read once per bounce.
+//   * the list is not scanned blindly: after the few big spheres, clusters of 8 spheres are
+//     tested only when some lane's ray reaches the cluster's bounding box (aabb.hpp slab test
+//     per lane + one __ballot), with a per-lane margin that covers the fp32 error of the
+//     sphere test so that the closest hit -- and the framebuffer -- stay bit-identical to the
+//     full scan (variant bit 4 is the full scan).
 //   * arithmetic: fp32, every fused multiply-add explicit (-ffp-contract=off), IEEE
 //     sqrt and divide, so results are bit-identical to the scalar restatement the
 //     tests check against.
