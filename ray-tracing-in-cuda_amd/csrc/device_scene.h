@@ -7,6 +7,7 @@
 //     box     [ncl] 2 x float4   inflated bounding box of each cluster (culling variant)
 //     rect    [nr]  2 x float4   {a0, a1, b0, b1} {k, axis(bits), 0, 0}
 //     cyl     [nc]  4 x float4   m_inv rows 0..2, {radius^2, zmin, zmax, 0}
+//     cbox    [nc]  2 x float4   world-space bounding box of each cylinder (culling variant)
 //   COLD part (stays in global memory / L2; read once per bounce by the winning lane)
 //     sphere  [ns]  1 x float4   {1/r, material(bits), list index(bits), 0}
 //     rect    [nr]  1 x float4   {material(bits), list index(bits), 0, 0}
@@ -63,6 +64,7 @@ struct RenderParams {
     int32_t ncl;             // clusters of 8 slots after the prefix, each with a bounding box
     int32_t off_box;         // 2 float4 per cluster: {min.xyz,_}, {max.xyz,_}
     int32_t ngr, off_gbox;   // outer boxes over RT_GROUP consecutive clusters
+    int32_t off_cbox;        // 2 float4 per cylinder: world-space bounding box of the open tube
     float cull_extent1;      // 1 + max |coordinate| of the clustered spheres (per-lane box margin, see packer)
     int32_t hot_vec4;        // float4 count of the hot part (LDS bytes / 16)
     int32_t off_rect_hot;    // float4 offsets inside the image

@@ -152,6 +152,8 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     off += 2 * L.nr;
     L.off_cyl_hot = off;
     off += 4 * L.nc;
+    L.off_cbox = off;
+    off += 2 * L.nc;
     L.hot_vec4 = off;
     L.off_sph_cold = off;
     off += ns_slots;
@@ -196,8 +198,30 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         const rt_prim &p = s.prims[slots[k]];
         for (int a = 0; a < 3; ++a) extent = std::max(extent, std::fabs(p.f[a]) + std::fabs(p.f[3]));
     }
+    // cylinders: world box of the open tube = union of the boxes of its two end circles
+    // (centre M (0,0,z), radius R, normal = the tube axis a: half-extent R sqrt(1 - a_i^2) on axis i)
+    std::vector<float> cyl_box((size_t)L.nc * 6);
+    for (int k = 0; k < L.nc; ++k) {
+        const rt_prim &p = s.prims[cyl[k]];
+        const double R = std::fabs((double)p.f[0]);
+        double ax[3] = {p.m[2], p.m[6], p.m[10]};  // image of the object z axis
+        const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        for (int a = 0; a < 3; ++a) {
+            const double ai = an > 0 ? ax[a] / an : 0.0;
+            const double half = R * std::sqrt(std::max(0.0, 1.0 - ai * ai));
+            const double c0 = p.m[a * 4 + 2] * (double)p.f[1] + p.m[a * 4 + 3];
+            const double c1 = p.m[a * 4 + 2] * (double)p.f[2] + p.m[a * 4 + 3];
+            const double lo = std::min(c0, c1) - half, hi = std::max(c0, c1) + half;
+            cyl_box[k * 6 + a] = (float)lo, cyl_box[k * 6 + 3 + a] = (float)hi;
+            extent = std::max(extent, (float)std::max(std::fabs(lo), std::fabs(hi)));
+        }
+    }
     L.cull_extent1 = extent + 1.0f;
     const float inflate = 1e-5f * (extent + 1.0f);
+    for (int k = 0; k < L.nc; ++k) {
+        float *b = rec4(L.off_cbox + 2 * k);
+        for (int a = 0; a < 3; ++a) b[a] = cyl_box[k * 6 + a] - inflate, b[4 + a] = cyl_box[k * 6 + 3 + a] + inflate;
+    }
     for (int q = 0; q < n_clusters; ++q) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = 0; k < RT_CLUSTER; ++k) {
@@ -380,8 +404,16 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
 
     int sample_first = o ? o->sample_first : 0;
     int sample_count = (o && o->sample_count > 0) ? o->sample_count : s.spp;
-    // samples per work item: scheduling only (the pixel sum is exact); 64 measured best on MI355X
-    int spp_chunk = (o && o->spp_chunk > 0) ? o->spp_chunk : 64;
+    // samples per work item: scheduling only (the pixel sum is exact).  64 measured best on MI355X for
+    // frames that fill the chip; small frames get smaller chunks so that there are a few items per
+    // resident wave (a 400x225 frame has 1450 tiles for ~6000 resident waves)
+    int spp_chunk = (o && o->spp_chunk > 0) ? o->spp_chunk : 0;
+    if (spp_chunk == 0) {
+        const long long tiles = (long long)((s.width + 7) / 8) * ((sh.local_rows + 7) / 8);
+        const long long want_items = 4LL * 256 * 6 * 4;  // 4 items per resident wave
+        spp_chunk = 64;
+        while (spp_chunk > 8 && tiles * ((sample_count + spp_chunk - 1) / spp_chunk) < want_items) spp_chunk /= 2;
+    }
     if (spp_chunk > sample_count) spp_chunk = sample_count;
     int num_chunks = (sample_count + spp_chunk - 1) / spp_chunk;
     if (sample_first < 0) {
@@ -529,7 +561,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         }
         HIP_TRY(hipMemsetAsync(ent->d_acc, 0, need, stream));
         unsigned int *d_queue = reinterpret_cast<unsigned int *>(ent->d_acc + plane);
-        launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, variant);
+        // nothing worth culling (no sphere clusters, a handful of cylinders): the plain scan is the
+        // same result without the per-query box set-up
+        unsigned launch_variant = variant;
+        if (!count && (variant & 16u) == 0 && P.ncl == 0 && P.nc < 4 && variant_exists(variant | 16u)) launch_variant = variant | 16u;
+        launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, launch_variant);
         launch_finalize(ent->d_acc, d_out, plane, stream);
         launches = 2;
     }

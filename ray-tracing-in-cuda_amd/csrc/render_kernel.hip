@@ -310,31 +310,32 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     RT_SPHERE_TEST(s, i)
                 }
             }
+            // ---- culling set-up (CULL): aabb::hit (aabb.hpp:15-29) for every live lane, then one wave-wide
+            // vote per box; used for the sphere clusters and for each cylinder's bounding box
+            // 1-ulp reciprocals are enough here: the box test only has to be conservative, and the
+            // margin below is five orders of magnitude larger than their error
+            const float idx = __builtin_amdgcn_rcpf(dx), idy = __builtin_amdgcn_rcpf(dy), idz = __builtin_amdgcn_rcpf(dz);
+            // per-lane box margin covering the fp32 error of the sphere test at this origin's
+            // distance (derivation in render_host.hip): two shifted origins, nothing per box
+            const float marg = 4e-3f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + P.cull_extent1);
+            // slab distances as one fma per face: t = b * (1/d) - (o +- marg) * (1/d).  The products
+            // cancel to an absolute error ~ eps |o/d|, i.e. ~1e-7 |o| in space: four orders of
+            // magnitude inside the margin.
+            const float nxm = -(ox + marg) * idx, nym = -(oy + marg) * idy, nzm = -(oz + marg) * idz;
+            const float nxp = -(ox - marg) * idx, nyp = -(oy - marg) * idy, nzp = -(oz - marg) * idz;
+            const float4 *box = lds + P.off_box;
+            const float4 *gbox = lds + P.off_gbox;
+            auto slab_live = [&](const float4 bmn, const float4 bmx) -> bool {
+                const float lx = fmaf(bmn.x, idx, nxm), ux = fmaf(bmx.x, idx, nxp);
+                const float ly = fmaf(bmn.y, idy, nym), uy = fmaf(bmx.y, idy, nyp);
+                const float lz = fmaf(bmn.z, idz, nzm), uz = fmaf(bmx.z, idz, nzp);
+                // live  <=>  tn <= tf, tf >= 0, tn <= best_t (1 + 1e-4)
+                //       <=>  max(tn, 0) <= min(tf, best_t (1 + 1e-4))          (NaN -> live)
+                const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
+                const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), best_t * 1.0001f), fmaxf(lz, uz));
+                return !(tn > tf);
+            };
             if (CULL) {
-                // clusters: aabb::hit (aabb.hpp:15-29) for every live lane, then one wave-wide vote
-                // 1-ulp reciprocals are enough here: the box test only has to be conservative, and the
-                // margin below is five orders of magnitude larger than their error
-                const float idx = __builtin_amdgcn_rcpf(dx), idy = __builtin_amdgcn_rcpf(dy), idz = __builtin_amdgcn_rcpf(dz);
-                // per-lane box margin covering the fp32 error of the sphere test at this origin's
-                // distance (derivation in render_host.hip): two shifted origins, nothing per box
-                const float marg = 4e-3f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + P.cull_extent1);
-                // slab distances as one fma per face: t = b * (1/d) - (o +- marg) * (1/d).  The products
-                // cancel to an absolute error ~ eps |o/d|, i.e. ~1e-7 |o| in space: four orders of
-                // magnitude inside the margin.
-                const float nxm = -(ox + marg) * idx, nym = -(oy + marg) * idy, nzm = -(oz + marg) * idz;
-                const float nxp = -(ox - marg) * idx, nyp = -(oy - marg) * idy, nzp = -(oz - marg) * idz;
-                const float4 *box = lds + P.off_box;
-                const float4 *gbox = lds + P.off_gbox;
-                auto slab_live = [&](const float4 bmn, const float4 bmx) -> bool {
-                    const float lx = fmaf(bmn.x, idx, nxm), ux = fmaf(bmx.x, idx, nxp);
-                    const float ly = fmaf(bmn.y, idy, nym), uy = fmaf(bmx.y, idy, nyp);
-                    const float lz = fmaf(bmn.z, idz, nzm), uz = fmaf(bmx.z, idz, nzp);
-                    // live  <=>  tn <= tf, tf >= 0, tn <= best_t (1 + 1e-4)
-                    //       <=>  max(tn, 0) <= min(tf, best_t (1 + 1e-4))          (NaN -> live)
-                    const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
-                    const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), best_t * 1.0001f), fmaxf(lz, uz));
-                    return !(tn > tf);
-                };
                 for (int g = 0; g < P.ngr; ++g) {
                 if (__builtin_amdgcn_ballot_w64(slab_live(gbox[2 * g], gbox[2 * g + 1])) == 0ull) continue;
                 if (COUNT) c_groups++;
@@ -381,6 +382,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
             // cylinders: cylinder::hit + quadratic, object.cuh:199-214, 233-290
             for (int k = 0; k < nc; ++k) {
+                if (CULL) {  // the cylinder's world-space box, same margin (the object-space quadratic has the
+                             // same error structure as the sphere test: ~1e-3 |o| in space)
+                    const float4 *cb = lds + P.off_cbox + 2 * k;
+                    if (__builtin_amdgcn_ballot_w64(slab_live(cb[0], cb[1])) == 0ull) continue;
+                }
                 const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2], pr = cyl[4 * k + 3];
                 const float oox = fmaf(r0.x, ox, fmaf(r0.y, oy, fmaf(r0.z, oz, r0.w)));
                 const float ooy = fmaf(r1.x, ox, fmaf(r1.y, oy, fmaf(r1.z, oz, r1.w)));

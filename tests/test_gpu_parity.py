@@ -19,6 +19,8 @@ TOL = 1e-3  # north_star: per-pixel max-abs error of the mean radiance
 def _scene(rtmi, scenes_dir, golden_dir, name):
     if name == "rtiow":
         return rtmi.Scene.load(os.path.join(golden_dir, "rtiow_seed7.json"))
+    if name == "dna":  # dna.py frame 30: 60 emissive spheres + 30 emissive rotated cylinders
+        return rtmi.Scene.dna(30.0)
     if name in ("three_sphere", "mixed_emissive"):
         return rtmi.Scene.load(os.path.join(scenes_dir, name + ".json"))
     return rtmi.Scene.load(os.path.join(golden_dir, "scenes", name + ".json"))
@@ -50,6 +52,7 @@ def test_device_present(rtmi):
     ("blue", 64, 36, 6),              # gpu-version/blue.json: rects, emissive cylinders, metal, glass
     ("blue2", 48, 27, 4),
     ("basic_scene", 40, 24, 2),       # ships with an EMPTY object list: pure background
+    ("dna", 80, 45, 4),               # config 2b: the DNA animation frame (cylinder boxes are culled)
 ])
 def test_bit_exact_vs_checker(rtmi, rtcheck, scenes_dir, golden_dir, name, w, h, spp):
     sc = _scene(rtmi, scenes_dir, golden_dir, name)
@@ -287,6 +290,12 @@ def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
     # the culled kernel really skips work: far fewer clusters visited than waves x clusters
     assert 0 < st.clusters_visited < 0.35 * st.wave_queries * st.cull_clusters
     assert st.cull_prefix == 8 and st.cull_cluster_size == 8 and st.cull_clusters == 60
-    # a second scene seed and the mixed scene (few spheres: everything sits in the prefix)
+    # a second scene seed, and the DNA frame (30 cylinders culled by their world-space boxes)
     sc2 = rtmi.Scene.rtiow(11, 960, 540, 16, 50)
     assert np.array_equal(sc2.render(rtmi.Opts(seed=3)), sc2.render(rtmi.Opts(seed=3, variant=16)))
+    sc3 = rtmi.Scene.dna(77.0)
+    sc3.override(width=1280, height=720, spp=32)
+    a = sc3.render(rtmi.Opts(seed=5))
+    assert np.array_equal(a, sc3.render(rtmi.Opts(seed=5, variant=16))) and a.max() > 0
+    ref, _ = rtcheck.oracle_render(rtcheck.OracleScene(sc3), seed=5, rows=(360, 362))
+    assert np.array_equal(a[360:362], ref[360:362])

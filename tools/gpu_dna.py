@@ -1,0 +1,17 @@
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+rtmi = load_package()
+sc = rtmi.Scene.dna(0.0); sc.override(width=1280, height=720, spp=256)   # BASELINE config 2b
+for v in (0, 16):
+    st = rtmi.Stats(); img = sc.render(rtmi.Opts(seed=2023, variant=v), st)
+    print(f"dna 1280x720x256 variant {v}: {st.kernel_ms:.2f} ms -> {1280*720*256/st.kernel_ms/1e3:.0f} Msamples/s mean {img.mean()/256:.4f}", flush=True)
+sc = rtmi.Scene.load(os.path.join(ROOT, "tests/golden/scenes/sample_scene.json")); sc.override(width=1920, height=1080, spp=512)
+for v in (0, 16):
+    st = rtmi.Stats(); img = sc.render(rtmi.Opts(seed=2023, variant=v), st)
+    print(f"sample_scene 1920x1080x512 variant {v}: {st.kernel_ms:.2f} ms -> {1920*1080*512/st.kernel_ms/1e3:.0f} Msamples/s", flush=True)
+sc = rtmi.Scene.load(os.path.join(ROOT, "ray-tracing-in-cuda_amd/scenes/three_sphere.json")); sc.override(width=400, height=225, spp=100)
+st = rtmi.Stats(); sc.render(rtmi.Opts(seed=2023), st); sc.render(rtmi.Opts(seed=2023), st)
+print(f"three_sphere 400x225x100: {st.kernel_ms:.3f} ms -> {400*225*100/st.kernel_ms/1e3:.0f} Msamples/s")
