@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--no-counts", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (16 = linear scan without AABB culling)")
+    ap.add_argument("--verify", action="store_true", help="rank 0 also renders the unsharded frame and checks the "
+                    "gathered one against it bit for bit (outside the timed region)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
     args = ap.parse_args()
 
@@ -166,6 +168,12 @@ def main():
             "render_seed": args.seed,
         },
     }
+
+    if rank == 0 and args.verify:
+        whole = scene.render(rtmi.Opts(seed=args.seed, device=dev_index, spp_chunk=chunk, variant=args.variant))
+        same = bool(np.array_equal(whole, img.cpu().numpy()))
+        result["config"]["gathered_equals_unsharded"] = same
+        assert same, "gathered row tiles differ from the unsharded frame"
 
     if rank == 0:
         # sanity of the measured frames themselves (not a parity test: those live in tests/)
