@@ -242,7 +242,10 @@ int rt_shard_global_row(const rt_scene *s, const rt_opts *o, int local_row);
  * gpu-version/main.cu:72-105 with its launch at :505-507.
  * d_rgb_sum: DEVICE pointer, rt_shard_rows()*W*3 floats, local rows dense.
  * stream: hipStream_t as void* (NULL = default stream). Asynchronous when
- * stats == NULL; with stats it records hipEvents and synchronises the stream. */
+ * stats == NULL; with stats it records hipEvents and synchronises the stream.
+ * One scene object keeps one set of device accumulators per device: overlapping
+ * renders of the SAME rt_scene on one device must be issued on the same stream
+ * (use rt_scene_clone for independent concurrent frames). */
 int rt_render_hip_device(const rt_scene *s, const rt_opts *o, void *d_rgb_sum, void *stream,
                          rt_stats *stats);
 

@@ -395,8 +395,6 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     rc = shard_of(s, o, sh);
     if (rc) return rc;
     if (stats) {
-        double keep = 0;
-        (void)keep;
         memset(stats, 0, sizeof *stats);
         stats->local_rows = sh.local_rows;
     }
@@ -463,7 +461,14 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         ent = &cache.entries.back();
         ent->device = device;
     }
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    struct Events {  // destroyed on every return path
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Events() {
+            for (hipEvent_t ev : e)
+                if (ev) (void)hipEventDestroy(ev);
+        }
+    } events;
+    hipEvent_t &ev0 = events.e[0], &ev1 = events.e[1], &ev2 = events.e[2];
     if (stats) {
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
@@ -550,7 +555,9 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         // while (depth > 0) never runs: every sample is black (main.cpp:20,42)
         HIP_TRY(hipMemsetAsync(d_out, 0, plane * sizeof(float), stream));
     } else {
-        // accumulators + the work-queue counter behind them, cleared together
+        // accumulators + the work-queue counter behind them, cleared together.  They belong to this
+        // (scene, device): concurrent renders of ONE scene object on one device must share a stream
+        // (different scene objects, or clones, are independent)
         const size_t need = plane * sizeof(unsigned long long) + 64;
         if (ent->acc_bytes < need) {
             if (ent->d_acc) HIP_TRY(hipFree(ent->d_acc));
@@ -580,9 +587,6 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         stats->upload_ms = up;
         stats->kernel_ms = k;
         stats->launches = launches;
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
-        (void)hipEventDestroy(ev2);
         if (count) {
             DevCounters h;
             HIP_TRY(hipMemcpy(&h, d_cnt, sizeof h, hipMemcpyDeviceToHost));
