@@ -103,7 +103,7 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         while (n_prefix < (int)sph.size() && std::fabs(s.prims[sph[n_prefix]].f[3]) > big) ++n_prefix;
     }
     for (int k = 0; k < n_prefix; ++k) slots.push_back(sph[k]);
-    while (slots.size() % 8) slots.push_back(-1);
+    while (slots.size() % 4) slots.push_back(-1);  // the prefix is walked four records at a time
     const int np_slots = (int)slots.size();
     std::vector<int> rest(sph.begin() + n_prefix, sph.end());
     if (!rest.empty()) {

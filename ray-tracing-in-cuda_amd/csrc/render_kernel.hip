@@ -285,13 +285,21 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
         if (__builtin_expect(cand, 0)) resolve(IDX, hb, disc);                                 \
     }
-            const int n_scan = CULL ? P.np : P.ns_pad;  // slots tested unconditionally
-            if (PREFETCH) {
-                // two register sets of four records, fetched one half-iteration ahead of their use;
-                // the table is padded to a multiple of 8 with never-hit records (r*r = -inf) plus 4
-                // more, so the fetches never leave the table
+            if (CULL) {
+                // the always-tested prefix (big spheres), four records at a time
+                for (int i = 0; i < P.np; i += 4) {
+                    const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
+                    RT_SPHERE_TEST(s0, i)
+                    RT_SPHERE_TEST(s1, i + 1)
+                    RT_SPHERE_TEST(s2, i + 2)
+                    RT_SPHERE_TEST(s3, i + 3)
+                }
+            } else if (PREFETCH) {
+                // flat scan of every slot: two register sets of four records, fetched one half-iteration
+                // ahead of their use; the table is padded to a multiple of 8 with never-hit records
+                // (r*r = -inf) plus 4 more, so the fetches never leave the table
                 float4 a0 = sph[0], a1 = sph[1], a2 = sph[2], a3 = sph[3];
-                for (int i = 0; i < n_scan; i += 8) {
+                for (int i = 0; i < P.ns_pad; i += 8) {
                     const float4 b0 = sph[i + 4], b1 = sph[i + 5], b2 = sph[i + 6], b3 = sph[i + 7];
                     RT_SPHERE_TEST(a0, i)
                     RT_SPHERE_TEST(a1, i + 1)
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 }
             } else {
 #pragma unroll 4
-                for (int i = 0; i < n_scan; ++i) {
+                for (int i = 0; i < P.ns_pad; ++i) {
                     const float4 s = sph[i];
                     RT_SPHERE_TEST(s, i)
                 }
@@ -325,6 +333,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             const float nxp = -(ox - marg) * idx, nyp = -(oy - marg) * idy, nzp = -(oz - marg) * idz;
             const float4 *box = lds + P.off_box;
             const float4 *gbox = lds + P.off_gbox;
+            // best_t (1 + 1e-4), refreshed whenever spheres have been tested (a stale, larger value only
+            // culls less)
+            float blim = best_t * 1.0001f;
             auto slab_live = [&](const float4 bmn, const float4 bmx) -> bool {
                 const float lx = fmaf(bmn.x, idx, nxm), ux = fmaf(bmx.x, idx, nxp);
                 const float ly = fmaf(bmn.y, idy, nym), uy = fmaf(bmx.y, idy, nyp);
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 // live  <=>  tn <= tf, tf >= 0, tn <= best_t (1 + 1e-4)
                 //       <=>  max(tn, 0) <= min(tf, best_t (1 + 1e-4))          (NaN -> live)
                 const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
-                const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), best_t * 1.0001f), fmaxf(lz, uz));
+                const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), blim), fmaxf(lz, uz));
                 return !(tn > tf);
             };
             if (CULL) {
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         for (int k = 0; k < RT_CLUSTER; ++k) rec[k] = cs[k];
 #pragma unroll
                         for (int k = 0; k < RT_CLUSTER; ++k) RT_SPHERE_TEST(rec[k], base + k)
+                        blim = best_t * 1.0001f;
                         if (COUNT) c_clusters++;
                     }
                 }
@@ -382,7 +394,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
             // cylinders: cylinder::hit + quadratic, object.cuh:199-214, 233-290
             for (int k = 0; k < nc; ++k) {
-                if (CULL) {  // the cylinder's world-space box, same margin (the object-space quadratic has the
+                if (CULL) {
+                    blim = best_t * 1.0001f;  // the cylinder's world-space box, same margin (the object-space quadratic has the
                              // same error structure as the sphere test: ~1e-3 |o| in space)
                     const float4 *cb = lds + P.off_cbox + 2 * k;
                     if (__builtin_amdgcn_ballot_w64(slab_live(cb[0], cb[1])) == 0ull) continue;

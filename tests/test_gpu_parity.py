@@ -289,7 +289,7 @@ def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
     st = sc.count(rtmi.Opts(seed=SEED))
     # the culled kernel really skips work: far fewer clusters visited than waves x clusters
     assert 0 < st.clusters_visited < 0.35 * st.wave_queries * st.cull_clusters
-    assert st.cull_prefix == 8 and st.cull_cluster_size == 8 and st.cull_clusters == 60
+    assert st.cull_prefix == 4 and st.cull_cluster_size == 8 and st.cull_clusters == 60
     # a second scene seed, and the DNA frame (30 cylinders culled by their world-space boxes)
     sc2 = rtmi.Scene.rtiow(11, 960, 540, 16, 50)
     assert np.array_equal(sc2.render(rtmi.Opts(seed=3)), sc2.render(rtmi.Opts(seed=3, variant=16)))
