@@ -331,8 +331,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             // magnitude inside the margin.
             const float nxm = -(ox + marg) * idx, nym = -(oy + marg) * idy, nzm = -(oz + marg) * idz;
             const float nxp = -(ox - marg) * idx, nyp = -(oy - marg) * idy, nzp = -(oz - marg) * idz;
-            const float4 *box = lds + P.off_box;
-            const float4 *gbox = lds + P.off_gbox;
+            const float4 *box = (SCALAR ? image : lds) + P.off_box;
+            const float4 *gbox = (SCALAR ? image : lds) + P.off_gbox;
             // best_t (1 + 1e-4), refreshed whenever spheres have been tested (a stale, larger value only
             // culls less)
             float blim = best_t * 1.0001f;
