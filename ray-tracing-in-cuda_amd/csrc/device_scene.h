@@ -30,6 +30,9 @@
 #define RT_GROUP 4
 #endif
 
+// most short chunks at the end of a launch's work queue
+#define RT_MAX_TAIL 16
+
 namespace rtmi {
 
 enum MatKind : int32_t {
@@ -55,7 +58,10 @@ struct RenderParams {
     // shard geometry (see rt_opts)
     int32_t tile_rows, tile_first, tile_stride, num_tiles, local_rows;
     // samples
-    int32_t sample_first, sample_count, spp_chunk, num_chunks;
+    // samples [sample_first, +sample_count) are cut into n_big chunks of spp_chunk followed by chunks of
+    // shrinking tail chunks (the last work items of a launch are short, so its tail is short); num_chunks = total
+    int32_t sample_first, sample_count, spp_chunk, num_chunks, n_big;
+    int32_t tail_off[RT_MAX_TAIL + 1];  // sample offsets (from the end of the big chunks) of the tail chunks
     uint32_t seed_lo, seed_hi;
     // scene image
     int32_t ns, nr, nc, nm;

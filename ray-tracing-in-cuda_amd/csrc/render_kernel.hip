@@ -123,13 +123,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     extern __shared__ float4 lds[];
     // stage the hot tables (hittable_list contents) into LDS
     for (int i = threadIdx.x; i < P.hot_vec4; i += 256) lds[i] = image[i];
-    // per-wave tile accumulators: 64 pixels x rgb, 64-bit fixed point
+    // per-wave tile accumulators (two: current and older work item): 64 pixels x rgb, 64-bit fixed point
     unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + P.hot_vec4);
-    for (int i = threadIdx.x; i < 4 * 64 * 3; i += 256) tile_acc[i] = 0ull;
+    for (int i = threadIdx.x; i < 4 * 2 * 64 * 3; i += 256) tile_acc[i] = 0ull;
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long *my_acc = tile_acc + wave * 192;
+    unsigned long long *my_acc = tile_acc + wave * 384;
     const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
     const float4 *sph = SCALAR ? image : lds;
     const float4 *rect = lds + P.off_rect_hot;
@@ -138,36 +138,49 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     const float wm1 = (float)(P.width - 1), hm1 = (float)(P.height - 1);
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
-    uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0, c_draws = 0;
+    uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0;
     uint32_t c_cand = 0, c_cand_wave = 0, c_clusters = 0, c_groups = 0, c_wave_queries = 0;
 
-    // ---- persistent waves: the grid only fills the chip; every wave pulls (8x8 tile, sample
-    // chunk) work items from one global counter until it runs dry, so no CU idles behind a slow
-    // tile and the tail of a launch is one item, whatever the frame or shard size.  From here
-    // on the four waves of the workgroup never synchronise again.
-    for (;;) {
-    unsigned int item = 0;
-    if (lane == 0) item = atomicAdd(queue, 1u);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= (unsigned int)P.num_items) break;  // the counter only grows: every wave gets here
-    const int tx = (int)(item % (unsigned int)P.tiles_x);
-    const int band = (int)((item / (unsigned int)P.tiles_x) % (unsigned int)P.bands);
-    const int chunk = (int)(item / ((unsigned int)P.tiles_x * (unsigned int)P.bands));
-    const int x0 = tx * 8;
-    // this lane's home pixel (the one it flushes at the end; with !POOL the one it renders)
-    const int hx = x0 + (lane & 7);
-    const int hlr = band * 8 + (lane >> 3);  // dense local row of this shard
-    const int htl = hlr / P.tile_rows;
-    const int hy = (P.tile_first + htl * P.tile_stride) * P.tile_rows + (hlr - htl * P.tile_rows);
-    const int hvalid = (hx < P.width && hlr < P.local_rows && hy < P.height) ? 1 : 0;
+    // ---- persistent waves, streaming work items.  The grid only fills the chip; every wave pulls
+    // (8x8 tile, sample chunk) work items from one global counter until it runs dry.  A wave does not
+    // drain an item before taking the next: when the pool of the CURRENT item is handed out, idle
+    // lanes start on the next item while the stragglers of the previous one (the OLDER item) finish;
+    // each of the two has its own tile accumulator in LDS, flushed when its last path ends.  So lanes
+    // only idle at the very end of the launch, and items can be short.  From here on the four waves
+    // of the workgroup never synchronise again.
+    unsigned long long *c_acc = my_acc;        // accumulator of the current item (wave-uniform pointers)
+    unsigned long long *o_acc = my_acc + 192;  //                 of the older item
+    int c_x0 = 0, c_band = 0, c_sbegin = 0, c_nsamp = 0, c_pool = 0, cursor = 0;
+    int o_x0 = 0, o_band = 0;
+    bool c_valid = false, o_busy = false, queue_empty = false;
+    int c_hy = 0, c_hvalid = 0;  // this lane's home pixel in the current item (row, on-image)
+    int mine = 0;                // !POOL: samples of the home pixel started so far (current item)
+    bool in_old = false;         // this lane's live path belongs to the older item
 
-    const int s_begin = P.sample_first + chunk * P.spp_chunk;
-    int s_stop = s_begin + P.spp_chunk;
-    if (s_stop > P.sample_first + P.sample_count) s_stop = P.sample_first + P.sample_count;
-    const int n_samples = s_stop - s_begin;  // wave-uniform
-    const int pool_items = n_samples * 64;   // item k = (pixel k & 63, sample s_begin + (k >> 6))
-    int cursor = 0;                          // POOL: wave-uniform pool cursor
-    int mine = 0;                            // !POOL: samples of the home pixel started so far
+    // home pixel of this lane in the tile (x0, band): column, dense local row, image row, on-image
+    auto home_pixel = [&](int x0, int band, int &hx, int &hlr, int &hy, int &hvalid) {
+        hx = x0 + (lane & 7);
+        hlr = band * 8 + (lane >> 3);
+        const int htl = hlr / P.tile_rows;
+        hy = (P.tile_first + htl * P.tile_stride) * P.tile_rows + (hlr - htl * P.tile_rows);
+        hvalid = (hx < P.width && hlr < P.local_rows && hy < P.height) ? 1 : 0;
+    };
+    // tile accumulator -> global accumulators (image[y*W + x] += res, main.cu:104; one 64-bit atomic per
+    // channel: other sample chunks of the same pixels are other work items), then clear it for reuse
+    auto flush_tile = [&](unsigned long long *tile, int x0, int band) {
+        int hx, hlr, hy, hvalid;
+        home_pixel(x0, band, hx, hlr, hy, hvalid);
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long *a = tile + lane * 3;
+        if (hvalid) {
+            unsigned long long *g = acc + ((size_t)hlr * P.width + hx) * 3;
+            atomicAdd(g + 0, a[0]);
+            atomicAdd(g + 1, a[1]);
+            atomicAdd(g + 2, a[2]);
+        }
+        a[0] = a[1] = a[2] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+    };
 
     LaneRng rng;
     rng.g.x = rng.g.y = rng.g.z = 0u, rng.g.w = 1u, rng.draws = 0;
@@ -184,27 +197,71 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         const bool need = !active;
         const unsigned long long idle = __ballot(need);
         if (idle) {  // wave-uniform
+            // is the current item handed out completely?
+            bool exhausted = !c_valid;
+            if (c_valid) {
+                if (POOL) exhausted = cursor >= c_pool;
+                else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine < c_nsamp) == 0ull;
+            }
+            // then take the next one, unless the older item still occupies the second accumulator
+            if (exhausted && !queue_empty && !(c_valid && o_busy)) {
+                unsigned int item = 0;
+                if (lane == 0) item = atomicAdd(queue, 1u);
+                item = __builtin_amdgcn_readfirstlane(item);
+                if (item >= (unsigned int)P.num_items) {
+                    queue_empty = true;  // the counter only grows: every wave gets here
+                } else {
+                    if (c_valid) {  // the current item becomes the older one; every live path is its
+                        o_x0 = c_x0, o_band = c_band;
+                        unsigned long long *t = c_acc;
+                        c_acc = o_acc, o_acc = t;
+                        o_busy = true;
+                        in_old = active;
+                    }
+                    c_x0 = (int)(item % (unsigned int)P.tiles_x) * 8;
+                    c_band = (int)((item / (unsigned int)P.tiles_x) % (unsigned int)P.bands);
+                    const int chunk = (int)(item / ((unsigned int)P.tiles_x * (unsigned int)P.bands));
+                    int s_stop;  // sample range: big chunks first, short ones at the end of the queue
+                    if (chunk < P.n_big) {
+                        c_sbegin = P.sample_first + chunk * P.spp_chunk;
+                        s_stop = c_sbegin + P.spp_chunk;
+                    } else {
+                        const int base = P.sample_first + P.n_big * P.spp_chunk, k = chunk - P.n_big;
+                        c_sbegin = base + P.tail_off[k];
+                        s_stop = base + P.tail_off[k + 1];
+                    }
+                    if (s_stop > P.sample_first + P.sample_count) s_stop = P.sample_first + P.sample_count;
+                    c_nsamp = s_stop - c_sbegin;
+                    c_pool = c_nsamp * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
+                    cursor = 0;
+                    mine = 0;
+                    c_valid = true;
+                    int hx_unused, hlr_unused;
+                    home_pixel(c_x0, c_band, hx_unused, hlr_unused, c_hy, c_hvalid);
+                }
+            }
             bool start = false;
             int sp = 0, spx = 0, spy = 0, ss = 0;
             if (POOL) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const int k = cursor + rank;
-                cursor = min(cursor + (int)__popcll(idle), pool_items);
+                if (c_valid) cursor = min(cursor + (int)__popcll(idle), c_pool);
                 sp = k & 63;
                 // row and validity of pixel sp live in lane sp's registers (all lanes take part)
-                spy = __shfl(hy, sp, 64);
-                const int pv = __shfl(hvalid, sp, 64);
-                spx = x0 + (sp & 7);
-                ss = s_begin + (k >> 6);
-                start = need && k < pool_items && pv != 0;
+                spy = __shfl(c_hy, sp, 64);
+                const int pv = __shfl(c_hvalid, sp, 64);
+                spx = c_x0 + (sp & 7);
+                ss = c_sbegin + (k >> 6);
+                start = need && c_valid && k < c_pool && pv != 0;
             } else {
-                start = need && mine < n_samples && hvalid != 0;
-                sp = lane, spx = hx, spy = hy, ss = s_begin + mine;
+                start = need && c_valid && mine < c_nsamp && c_hvalid != 0;
+                sp = lane, spx = c_x0 + (lane & 7), spy = c_hy, ss = c_sbegin + mine;
                 if (start) mine++;
             }
             if (start) {
                 cur_p = sp;
+                in_old = false;
                 rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss, k0, k1);
                 float u = ((float)spx + rng_next<COUNT>(rng)) / wm1;
                 float v = ((float)spy + rng_next<COUNT>(rng)) / hm1;
@@ -238,9 +295,24 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 if (COUNT) c_samples++;
             }
         }
+        // the older item retires when its last path has ended
+        if (o_busy && __builtin_amdgcn_ballot_w64(active && in_old) == 0ull) {
+            flush_tile(o_acc, o_x0, o_band);
+            o_busy = false;
+        }
         if (!__any(active)) {
-            // no lane found work: done, unless the pool only handed out off-image pixels so far
-            if (!POOL || cursor >= pool_items) break;
+            // nothing in flight (so the older item is already flushed).  Out of work when the queue is
+            // dry and the current item is handed out; otherwise loop: the refill above makes progress
+            // every time (takes an item, marks the queue empty, or skips off-image pool entries).
+            bool exhausted = !c_valid;
+            if (c_valid) {
+                if (POOL) exhausted = cursor >= c_pool;
+                else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine < c_nsamp) == 0ull;
+            }
+            if (queue_empty && exhausted) {
+                if (c_valid) flush_tile(c_acc, c_x0, c_band);
+                break;
+            }
             continue;
         }
 
@@ -608,7 +680,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 if (COUNT) c_misses++;
             }
             if (path_done) {  // res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
-                unsigned long long *a = my_acc + cur_p * 3;
+                unsigned long long *a = (in_old ? o_acc : c_acc) + cur_p * 3;
                 atomicAdd(a + 0, radiance_to_fixed(L_r));
                 atomicAdd(a + 1, radiance_to_fixed(L_g));
                 atomicAdd(a + 2, radiance_to_fixed(L_b));
@@ -616,22 +688,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             }
         }
     }
-
-    // ---- tile -> global accumulators (image[y*W + x] += res; one 64-bit atomic per channel:
-    // other sample chunks of the same pixels are other work items), and clear for the next item
-    __builtin_amdgcn_wave_barrier();
-    {
-        unsigned long long *a = my_acc + lane * 3;
-        if (hvalid) {
-            unsigned long long *g = acc + ((size_t)hlr * P.width + hx) * 3;
-            atomicAdd(g + 0, a[0]);
-            atomicAdd(g + 1, a[1]);
-            atomicAdd(g + 2, a[2]);
-        }
-        a[0] = a[1] = a[2] = 0ull;
-    }
-    if (COUNT) c_draws += rng.draws;
-    }  // work items
 
     if (COUNT) {
         // one atomic per wave per counter
@@ -648,7 +704,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         wave_add(&counters->scatter[1], c_scatter1);
         wave_add(&counters->scatter[2], c_scatter2);
         wave_add(&counters->scatter[3], c_scatter3);
-        wave_add(&counters->rng_draws, c_draws);
+        wave_add(&counters->rng_draws, rng.draws);
         wave_add(&counters->cand_lanes, c_cand);
         wave_add(&counters->cand_waves, c_cand_wave);
         if (lane == 0 && c_clusters) atomicAdd(&counters->clusters_visited, (unsigned long long)c_clusters);
