@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2023)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=64)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (16 = linear scan without AABB culling)")
     ap.add_argument("--verify", action="store_true", help="rank 0 also renders the unsharded frame and checks the "
                     "gathered one against it bit for bit (outside the timed region)")
@@ -126,9 +126,9 @@ def main():
         torch.cuda.synchronize()
 
     # one-time set-up outside any timed or warm-up step: scene image upload, accumulator allocation and
-    # occupancy query (a one-sample render), and the communicator's first collective
+    # occupancy query, and the communicator's first collective.  It is the same launch as a step, so that
+    # every render_kernel row of a `rocprofv3 --stats` summary of this command is one step's launch.
     prime = rdist.shard_opts(base, rank, world)
-    prime.sample_count = 1
     scene.render_device(prime, local.data_ptr(), stream, rtmi.Stats())
     rdist.gather_framebuffer(local, scene, base, rank, world, out=full, via_host=args.backend != "nccl")
 
