@@ -258,6 +258,21 @@ int rt_render_hip(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats 
  * rgb_sum may be NULL. */
 int rt_render_hip_count(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats *stats);
 
+/* Progressive / resumable rendering (the reference's only analogue is the running
+ * average of the Taichi renderers, taichi-version/4_0_path_tracing.py).  `acc` is the caller's
+ * exact pixel sums for this shard, [local_rows][width][3] signed 64-bit fixed point in units of
+ * 2^-32 (zero-initialised before the first call).  The call adds the samples
+ * [sample_first, sample_first + sample_count) of `o` to it; integer addition is exact and
+ * commutative, so any split of a sample range into calls, processes or devices gives the same
+ * sums -- and the same framebuffer -- as one rt_render_hip call over the whole range.
+ * If rgb_sum is not NULL it receives the fp32 framebuffer of the updated sums. */
+int rt_render_hip_accumulate(const rt_scene *s, const rt_opts *o, int64_t *acc, float *rgb_sum,
+                             rt_stats *stats);
+
+/* fp32 framebuffer values of exact sums: rgb_sum[i] = (float)(acc[i] * 2^-32), the conversion the
+ * render path itself applies once per launch. */
+void rt_acc_to_rgb(const int64_t *acc, float *rgb_sum, size_t n_values);
+
 /* scatter a shard's dense local rows into a full-image buffer (host side of
  * the multi-GPU gather; also used after the RCCL gather on the root). */
 int rt_shard_scatter_rows(const rt_scene *s, const rt_opts *o, const float *local_rgb,

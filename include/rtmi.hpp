@@ -206,6 +206,22 @@ public:
         check(rt_render_hip(s_, &o, img.data(), stats), "render");
         return img;
     }
+    // progressive rendering: adds samples [first, first + count) to the caller's exact pixel sums
+    // (resized and zeroed when empty) and returns the framebuffer of the updated sums
+    std::vector<float> accumulate(std::vector<int64_t> &acc, int first, int count, const rt_opts *opts = nullptr,
+                                  rt_stats *stats = nullptr) const {
+        rt_opts o;
+        if (opts) o = *opts;
+        else rt_opts_default(&o);
+        o.sample_first = first, o.sample_count = count;
+        const rt_scene_info i = info();
+        const size_t n = (size_t)rt_shard_rows(s_, &o) * i.width * 3;
+        if (acc.empty()) acc.assign(n, 0);
+        if (acc.size() != n) throw std::runtime_error("rtmi: accumulate: accumulator size does not match the shard");
+        std::vector<float> img(n);
+        check(rt_render_hip_accumulate(s_, &o, acc.data(), img.data(), stats), "accumulate");
+        return img;
+    }
     rt_scene *handle() const { return s_; }
 
 private:

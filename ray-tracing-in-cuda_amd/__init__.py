@@ -158,6 +158,8 @@ _sig("rt_shard_global_row", C.c_int, _p, C.POINTER(Opts), C.c_int)
 _sig("rt_render_hip_device", C.c_int, _p, C.POINTER(Opts), _p, _p, C.POINTER(Stats))
 _sig("rt_render_hip", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
 _sig("rt_render_hip_count", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
+_sig("rt_render_hip_accumulate", C.c_int, _p, C.POINTER(Opts), _p, _p, C.POINTER(Stats))
+_sig("rt_acc_to_rgb", None, _p, _p, C.c_size_t)
 _sig("rt_shard_scatter_rows", C.c_int, _p, C.POINTER(Opts), _p, _p)
 _sig("rt_write_ppm", C.c_int, C.c_char_p, _p, C.c_int, C.c_int, C.c_int)
 _sig("rt_quantize_rgb8", C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p)
@@ -175,7 +177,8 @@ C_SYMBOLS = [
     "rt_scene_add_diffuse_light", "rt_scene_add_sphere", "rt_scene_add_rect", "rt_scene_add_cylinder",
     "rt_scene_override", "rt_scene_get_info", "rt_scene_get_camera", "rt_scene_get_prims",
     "rt_scene_get_materials", "rt_scene_get_textures", "rt_shard_rows", "rt_shard_global_row",
-    "rt_render_hip_device", "rt_render_hip", "rt_render_hip_count", "rt_shard_scatter_rows", "rt_write_ppm",
+    "rt_render_hip_device", "rt_render_hip", "rt_render_hip_count", "rt_render_hip_accumulate",
+    "rt_acc_to_rgb", "rt_shard_scatter_rows", "rt_write_ppm",
     "rt_quantize_rgb8", "rt_philox4x32_10", "rt_aabb_hit", "rt_sample_stream", "rt_write_png",
     "rt_scene_output_file", "rt_scene_rotate_cylinders", "rt_scene_set_output_file", "rt_scene_dna", "rt_scene_clone",
 ]
@@ -399,11 +402,36 @@ class Scene:
         _check(_lib.rt_render_hip_count(self._h, C.byref(opts), ptr, C.byref(st)), "rt_render_hip_count")
         return (st, out) if want_image else st
 
+    def accumulate(self, acc: np.ndarray | None = None, opts: Opts | None = None, stats: Stats | None = None,
+                   want_image=True):
+        """Progressive rendering: add the samples [opts.sample_first, +sample_count) to the exact pixel sums
+        `acc` (int64 [local_rows, width, 3], 2^-32 units; None = start from zero).  Returns (acc, image)."""
+        opts = opts or Opts()
+        rows = self.shard_rows(opts)
+        if acc is None:
+            acc = np.zeros((rows, self.width, 3), dtype=np.int64)
+        if acc.dtype != np.int64 or acc.shape != (rows, self.width, 3) or not acc.flags.c_contiguous:
+            raise ValueError(f"acc must be a C-contiguous int64 array of shape {(rows, self.width, 3)}")
+        out = np.empty((rows, self.width, 3), dtype=np.float32) if want_image else None
+        _check(_lib.rt_render_hip_accumulate(self._h, C.byref(opts), acc.ctypes.data_as(C.c_void_p),
+                                             out.ctypes.data_as(C.c_void_p) if want_image else None,
+                                             C.byref(stats) if stats is not None else None),
+               "rt_render_hip_accumulate")
+        return acc, out
+
     def scatter_rows(self, opts: Opts, local: np.ndarray, full: np.ndarray):
         local = np.ascontiguousarray(local, dtype=np.float32)
         assert full.dtype == np.float32 and full.flags.c_contiguous
         _check(_lib.rt_shard_scatter_rows(self._h, C.byref(opts), local.ctypes.data_as(C.c_void_p),
                                           full.ctypes.data_as(C.c_void_p)), "rt_shard_scatter_rows")
+
+
+def acc_to_rgb(acc: np.ndarray) -> np.ndarray:
+    """fp32 framebuffer values of exact int64 pixel sums (2^-32 units)."""
+    acc = np.ascontiguousarray(acc, dtype=np.int64)
+    out = np.empty(acc.shape, dtype=np.float32)
+    _lib.rt_acc_to_rgb(acc.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), acc.size)
+    return out
 
 
 def _guess_status() -> int:

@@ -442,6 +442,12 @@ static inline int quantize(float sum, int spp, int gamma) {
     return (int)(256.0f * v);
 }
 
+void rt_acc_to_rgb(const int64_t *acc, float *rgb_sum, size_t n_values) {
+    if (!acc || !rgb_sum) return;
+    // same expression as the device's finalize step (render_kernel.hip): exact in double, one rounding to float
+    for (size_t i = 0; i < n_values; ++i) rgb_sum[i] = (float)((double)acc[i] * (1.0 / 4294967296.0));
+}
+
 int rt_quantize_rgb8(const float *rgb_sum, int width, int height, int spp, int gamma, uint8_t *out) {
     if (!rgb_sum || !out || width <= 0 || height <= 0 || spp <= 0) {
         set_error("rt_quantize_rgb8: bad argument");

@@ -4,8 +4,11 @@
 //   gpu-version   `parallel_compute -f scene.json`            (main.cu:455-460) -> main.ppm
 //   cmake-cpu     `ray_tracing -w W -h H -d DEPTH -spp N`     (main.cpp:71-81)  -> main.ppm
 // plus --rtiow [--scene-seed S] (the hard-coded random_scene() of main.cpp:125-172),
-// --seed, -o, --device, --chunk, --no-blur, --sky, --dump-json.  Timing goes to stderr
-// like the reference's when() markers (rtweekend.cuh:40).
+// --seed, -o, --device, --chunk, --dump-json.  Timing goes to stderr like the reference's
+// when() markers (rtweekend.cuh:40).
+// Resumable rendering: --acc-out FILE saves the exact pixel sums, --acc-in FILE continues from them
+// (-spp is then the number of samples to ADD; --spp-begin overrides the first sample index).  Any
+// split of a sample range into runs writes the same main.ppm as one run over the whole range.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +18,16 @@
 
 #include "../../include/rtmi.h"
 
+// exact pixel sums on disk: 40-byte header + int64[height][width][3], little endian
+struct AccHeader {
+    char magic[8];  // "RTMIACC1"
+    int32_t width, height;
+    int64_t samples_done;  // samples [0, samples_done) are in the sums
+    uint64_t seed;
+    int64_t reserved;
+};
+static_assert(sizeof(AccHeader) == 40, "accumulator file header");
+
 static double now_s() {
     using namespace std::chrono;
     return duration<double>(steady_clock::now().time_since_epoch()).count();
@@ -23,7 +36,8 @@ static double now_s() {
 static int usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [-f scene.json | --rtiow] [-w W] [-h H] [-d DEPTH] [-spp N] [-o out.ppm]\n"
-            "          [--seed S] [--scene-seed S] [--device N] [--chunk N] [--dump-json file] [--count] [--no-png]\n",
+            "          [--seed S] [--scene-seed S] [--device N] [--chunk N] [--dump-json file] [--count] [--no-png]\n"
+            "          [--acc-in sums.bin] [--acc-out sums.bin] [--spp-begin FIRST]\n",
             argv0);
     return 2;
 }
@@ -31,7 +45,8 @@ static int usage(const char *argv0) {
 int main(int argc, char **argv) {
     std::string scene_file = "sample_scene.json";  // main.cu:456 default
     std::string out_file = "main.ppm";             // main.cu:512
-    std::string dump_json;
+    std::string dump_json, acc_in, acc_out;
+    long long spp_begin = -1;
     bool rtiow = false, have_file = false, count = false, no_png = false;
     int w = 0, h = 0, depth = 0, spp = 0, device = 0, chunk = 0;
     unsigned long long seed = 2023;
@@ -55,6 +70,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--device")) device = atoi(need("--device"));
         else if (!strcmp(argv[i], "--chunk")) chunk = atoi(need("--chunk"));
         else if (!strcmp(argv[i], "--dump-json")) dump_json = need("--dump-json");
+        else if (!strcmp(argv[i], "--acc-in")) acc_in = need("--acc-in");
+        else if (!strcmp(argv[i], "--acc-out")) acc_out = need("--acc-out");
+        else if (!strcmp(argv[i], "--spp-begin")) spp_begin = atoll(need("--spp-begin"));
         else if (!strcmp(argv[i], "--rtiow")) rtiow = true;
         else if (!strcmp(argv[i], "--count")) count = true;
         else if (!strcmp(argv[i], "--no-png")) no_png = true;
@@ -101,7 +119,62 @@ int main(int argc, char **argv) {
     o.spp_chunk = chunk;
     rt_stats st;
     std::vector<float> img((size_t)info.width * info.height * 3);
-    int rc = count ? rt_render_hip_count(sc, &o, img.data(), &st) : rt_render_hip(sc, &o, img.data(), &st);
+    int total_spp = info.samples_per_pixel;  // divisor of the written image
+    int rc;
+    const bool progressive = !acc_in.empty() || !acc_out.empty() || spp_begin >= 0;
+    if (progressive) {
+        if (count) {
+            fprintf(stderr, "rtmi: --count cannot be combined with --acc-in/--acc-out/--spp-begin\n");
+            return 2;
+        }
+        std::vector<int64_t> acc(img.size(), 0);
+        long long done = 0;
+        if (!acc_in.empty()) {
+            FILE *fp = fopen(acc_in.c_str(), "rb");
+            AccHeader h;
+            if (!fp || fread(&h, sizeof h, 1, fp) != 1 || memcmp(h.magic, "RTMIACC1", 8) != 0) {
+                fprintf(stderr, "rtmi: %s is not an accumulator file\n", acc_in.c_str());
+                return 1;
+            }
+            if (h.width != info.width || h.height != info.height || h.seed != seed) {
+                fprintf(stderr, "rtmi: %s holds %dx%d sums of seed %llu, this run is %dx%d seed %llu\n", acc_in.c_str(),
+                        h.width, h.height, (unsigned long long)h.seed, info.width, info.height, seed);
+                return 1;
+            }
+            if (fread(acc.data(), sizeof(int64_t), acc.size(), fp) != acc.size()) {
+                fprintf(stderr, "rtmi: %s is truncated\n", acc_in.c_str());
+                return 1;
+            }
+            fclose(fp);
+            done = h.samples_done;
+        }
+        if (spp_begin < 0) spp_begin = done;
+        if (spp_begin != done) {
+            fprintf(stderr, "rtmi: the sums hold samples [0, %lld) but --spp-begin is %lld\n", done, spp_begin);
+            return 1;
+        }
+        if (spp_begin + info.samples_per_pixel > 0x7fffffffLL) {
+            fprintf(stderr, "rtmi: sample index overflow\n");
+            return 1;
+        }
+        o.sample_first = (int)spp_begin;
+        o.sample_count = info.samples_per_pixel;
+        rc = rt_render_hip_accumulate(sc, &o, acc.data(), img.data(), &st);
+        total_spp = (int)(spp_begin + info.samples_per_pixel);
+        if (rc == RT_OK && !acc_out.empty()) {
+            AccHeader h = {{'R', 'T', 'M', 'I', 'A', 'C', 'C', '1'}, info.width, info.height, total_spp, seed, 0};
+            FILE *fp = fopen(acc_out.c_str(), "wb");
+            if (!fp || fwrite(&h, sizeof h, 1, fp) != 1 ||
+                fwrite(acc.data(), sizeof(int64_t), acc.size(), fp) != acc.size() || fclose(fp) != 0) {
+                fprintf(stderr, "rtmi: cannot write %s\n", acc_out.c_str());
+                return 1;
+            }
+        }
+        if (rc == RT_OK)
+            fprintf(stderr, "progressive: samples [%lld, %d) added, image holds %d spp\n", spp_begin, total_spp, total_spp);
+    } else {
+        rc = count ? rt_render_hip_count(sc, &o, img.data(), &st) : rt_render_hip(sc, &o, img.data(), &st);
+    }
     if (rc != RT_OK) {
         fprintf(stderr, "rtmi: render failed: %s: %s\n", rt_status_string(rc), rt_last_error());
         return 1;
@@ -113,7 +186,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "counts: samples %llu queries %llu prim_tests %llu hits %llu misses %llu draws %llu\n",
                 (unsigned long long)st.samples, (unsigned long long)st.queries, (unsigned long long)st.prim_tests,
                 (unsigned long long)st.hits, (unsigned long long)st.misses, (unsigned long long)st.rng_draws);
-    if (rt_write_ppm(out_file.c_str(), img.data(), info.width, info.height, info.samples_per_pixel) != RT_OK) {
+    if (rt_write_ppm(out_file.c_str(), img.data(), info.width, info.height, total_spp) != RT_OK) {
         fprintf(stderr, "rtmi: %s\n", rt_last_error());
         return 1;
     }
@@ -121,7 +194,7 @@ int main(int argc, char **argv) {
     // directory of output_file does not exist, which the reference would crash on)
     if (!no_png) {
         const char *png = rt_scene_output_file(sc);
-        if (rt_write_png(png, img.data(), info.width, info.height, info.samples_per_pixel, 0) != RT_OK)
+        if (rt_write_png(png, img.data(), info.width, info.height, total_spp, 0) != RT_OK)
             fprintf(stderr, "rtmi: PNG not written: %s\n", rt_last_error());
     }
     fprintf(stderr, "Program finish, cost: %f s\n", now_s() - t0);  // main.cu:519-520

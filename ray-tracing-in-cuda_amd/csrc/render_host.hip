@@ -384,8 +384,8 @@ int rt_device_count(void) {
 }
 
 static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, void *stream_v, rt_stats *stats,
-                       bool count) {
-    if (!sc || !d_rgb_sum) {
+                       long long *h_acc, bool count) {
+    if (!sc || (!d_rgb_sum && !h_acc)) {
         set_error("rt_render_hip_device: null scene or output pointer");
         return RT_ERR_ARG;
     }
@@ -586,7 +586,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     if (stats) HIP_TRY(hipEventRecord(ev1, stream));
 
     int launches = 0;
-    if (s.max_depth <= 0) {
+    if (s.max_depth <= 0 && !h_acc) {
         // while (depth > 0) never runs: every sample is black (main.cpp:20,42)
         HIP_TRY(hipMemsetAsync(d_out, 0, plane * sizeof(float), stream));
     } else {
@@ -602,14 +602,25 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             ent->acc_bytes = need;
         }
         HIP_TRY(hipMemsetAsync(ent->d_acc, 0, need, stream));
+        // progressive rendering: continue from the caller's exact sums
+        if (h_acc) HIP_TRY(hipMemcpyAsync(ent->d_acc, h_acc, plane * sizeof(long long), hipMemcpyHostToDevice, stream));
         unsigned int *d_queue = reinterpret_cast<unsigned int *>(ent->d_acc + plane);
         // nothing worth culling (no sphere clusters, a handful of cylinders): the plain scan is the
         // same result without the per-query box set-up
         unsigned launch_variant = variant;
         if (!count && (variant & 16u) == 0 && P.ncl == 0 && P.nc < 4 && variant_exists(variant | 16u)) launch_variant = variant | 16u;
-        launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, launch_variant);
-        launch_finalize(ent->d_acc, d_out, plane, stream);
-        launches = 2;
+        if (s.max_depth > 0) {
+            launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, launch_variant);
+            ++launches;
+        }
+        if (d_out) {
+            launch_finalize(ent->d_acc, d_out, plane, stream);
+            ++launches;
+        }
+        if (h_acc) {
+            HIP_TRY(hipMemcpyAsync(h_acc, ent->d_acc, plane * sizeof(long long), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
     }
     HIP_TRY(hipGetLastError());
 
@@ -645,10 +656,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
 }
 
 int rt_render_hip_device(const rt_scene *s, const rt_opts *o, void *d_rgb_sum, void *stream, rt_stats *stats) {
-    return render_impl(s, o, d_rgb_sum, stream, stats, false);
+    return render_impl(s, o, d_rgb_sum, stream, stats, nullptr, false);
 }
 
-static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_sum, rt_stats *stats, bool count) {
+static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_sum, rt_stats *stats, bool count,
+                              long long *h_acc = nullptr) {
     if (!sc) {
         set_error("null scene");
         return RT_ERR_ARG;
@@ -657,7 +669,7 @@ static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_s
         set_error("rt_render_hip_count needs a stats pointer");
         return RT_ERR_ARG;
     }
-    if (!count && !rgb_sum) {
+    if (!count && !rgb_sum && !h_acc) {
         set_error("null output buffer");
         return RT_ERR_ARG;
     }
@@ -681,8 +693,8 @@ static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_s
     const size_t bytes = (size_t)sh.local_rows * sc->s.width * 3 * sizeof(float);
     float *d_out = nullptr;
     rt_stats local;
-    if (bytes) HIP_TRY(hipMalloc((void **)&d_out, bytes));
-    rc = bytes ? render_impl(sc, o, d_out, nullptr, stats ? stats : &local, count) : RT_OK;
+    if (bytes && (rgb_sum || !h_acc)) HIP_TRY(hipMalloc((void **)&d_out, bytes));
+    rc = bytes ? render_impl(sc, o, d_out, nullptr, stats ? stats : &local, h_acc, count) : RT_OK;
     if (rc == RT_OK && rgb_sum && bytes) {
         hipError_t e = hipMemcpy(rgb_sum, d_out, bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
@@ -701,6 +713,15 @@ int rt_render_hip(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats 
 
 int rt_render_hip_count(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats *stats) {
     return render_host_buffer(s, o, rgb_sum, stats, true);
+}
+
+int rt_render_hip_accumulate(const rt_scene *s, const rt_opts *o, int64_t *acc, float *rgb_sum, rt_stats *stats) {
+    if (!acc) {
+        set_error("rt_render_hip_accumulate: null accumulator");
+        return RT_ERR_ARG;
+    }
+    static_assert(sizeof(long long) == sizeof(int64_t), "accumulator width");
+    return render_host_buffer(s, o, rgb_sum, stats, false, reinterpret_cast<long long *>(acc));
 }
 
 }  // extern "C"
