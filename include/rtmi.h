@@ -228,6 +228,10 @@ typedef struct rt_stats {
     uint64_t clusters_visited;       /* culling: sphere clusters a wave actually tested */
     uint64_t wave_queries;           /* closest-hit queries executed, counted per WAVE */
     uint64_t groups_visited;         /* culling: outer boxes that passed, per wave */
+    uint64_t lane_clusters;          /* culling: cluster boxes that passed, per LANE (what each ray needs) */
+    uint64_t lane_groups;            /* culling: outer boxes that passed, per LANE */
+    uint64_t group_maxpop;           /* culling: max over lanes of needed clusters, summed over visited groups */
+    uint64_t query_maxpop;           /* culling: max over lanes of needed clusters, summed over wave-queries */
     int32_t cull_prefix, cull_clusters, cull_groups, cull_cluster_size; /* table geometry */
 } rt_stats;
 

@@ -102,7 +102,9 @@ class Stats(C.Structure):
         ("samples", C.c_uint64), ("queries", C.c_uint64), ("prim_tests", C.c_uint64), ("hits", C.c_uint64),
         ("misses", C.c_uint64), ("scatter", C.c_uint64 * 4), ("rng_draws", C.c_uint64),
         ("cand_lanes", C.c_uint64), ("cand_waves", C.c_uint64), ("clusters_visited", C.c_uint64),
-        ("wave_queries", C.c_uint64), ("groups_visited", C.c_uint64), ("cull_prefix", C.c_int32),
+        ("wave_queries", C.c_uint64), ("groups_visited", C.c_uint64), ("lane_clusters", C.c_uint64),
+        ("lane_groups", C.c_uint64), ("group_maxpop", C.c_uint64), ("query_maxpop", C.c_uint64),
+        ("cull_prefix", C.c_int32),
         ("cull_clusters", C.c_int32), ("cull_groups", C.c_int32), ("cull_cluster_size", C.c_int32),
     ]
 

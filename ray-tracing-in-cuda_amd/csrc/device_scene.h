@@ -91,6 +91,8 @@ struct DevCounters {
     unsigned long long cand_lanes, cand_waves;  // sphere candidates resolved: per lane / per wave entry
     unsigned long long clusters_visited;         // culling: clusters whose spheres were tested (per wave)
     unsigned long long groups_visited;           // culling: outer boxes that passed (per wave)
+    unsigned long long lane_clusters, lane_groups;  // culling: boxes that passed, per lane
+    unsigned long long group_maxpop, query_maxpop;  // culling: max over lanes of needed clusters, per visited group / per wave-query
     unsigned long long wave_queries;             // closest-hit queries executed per wave (loop iterations)
 };
 

@@ -647,6 +647,10 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->cand_waves = h.cand_waves;
             stats->clusters_visited = h.clusters_visited;
             stats->groups_visited = h.groups_visited;
+            stats->lane_clusters = h.lane_clusters;
+            stats->lane_groups = h.lane_groups;
+            stats->group_maxpop = h.group_maxpop;
+            stats->query_maxpop = h.query_maxpop;
             stats->wave_queries = h.wave_queries;
             stats->cull_prefix = P.np, stats->cull_clusters = P.ncl, stats->cull_groups = P.ngr;
             stats->cull_cluster_size = RT_CLUSTER;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
     uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0;
-    uint32_t c_cand = 0, c_cand_wave = 0, c_clusters = 0, c_groups = 0, c_wave_queries = 0;
+    uint32_t c_cand = 0, c_cand_wave = 0, c_clusters = 0, c_groups = 0, c_wave_queries = 0, c_lane_clusters = 0, c_lane_groups = 0, c_group_maxpop = 0, c_query_maxpop = 0;
 
     // ---- persistent waves, streaming work items.  The grid only fills the chip; every wave pulls
     // (8x8 tile, sample chunk) work items from one global counter until it runs dry.  A wave does not
@@ -419,12 +419,20 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 return !(tn > tf);
             };
             if (CULL) {
+                uint32_t q_mine = 0;  // COUNT: clusters this lane's ray needs in this query
+                auto wave_max = [&](uint32_t v) {
+                    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+                    return v;
+                };
                 for (int g = 0; g < P.ngr; ++g) {
-                if (__builtin_amdgcn_ballot_w64(slab_live(gbox[2 * g], gbox[2 * g + 1])) == 0ull) continue;
-                if (COUNT) c_groups++;
+                uint32_t g_mine = 0;
+                const bool glive = slab_live(gbox[2 * g], gbox[2 * g + 1]);
+                if (__builtin_amdgcn_ballot_w64(glive) == 0ull) continue;
+                if (COUNT) c_groups++, c_lane_groups += glive ? 1u : 0u;
                 const int q_end = min(P.ncl, (g + 1) * RT_GROUP);
                 for (int q = g * RT_GROUP; q < q_end; ++q) {
                     const bool live = slab_live(box[2 * q], box[2 * q + 1]);
+                    if (COUNT && live && glive) c_lane_clusters++, q_mine++, g_mine++;
                     if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
                         const int base = P.np + RT_CLUSTER * q;
                         const float4 *cs = sph + base;
@@ -437,6 +445,14 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         if (COUNT) c_clusters++;
                     }
                 }
+                if (COUNT) {
+                    const uint32_t m = wave_max(g_mine);
+                    if (lane == 0) c_group_maxpop += m;
+                }
+                }
+                if (COUNT) {
+                    const uint32_t m = wave_max(q_mine);
+                    if (lane == 0) c_query_maxpop += m;
                 }
             }
 #undef RT_SPHERE_TEST
@@ -709,6 +725,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         wave_add(&counters->cand_waves, c_cand_wave);
         if (lane == 0 && c_clusters) atomicAdd(&counters->clusters_visited, (unsigned long long)c_clusters);
         if (lane == 0 && c_groups) atomicAdd(&counters->groups_visited, (unsigned long long)c_groups);
+        wave_add(&counters->lane_clusters, c_lane_clusters);
+        wave_add(&counters->lane_groups, c_lane_groups);
+        wave_add(&counters->group_maxpop, c_group_maxpop);
+        wave_add(&counters->query_maxpop, c_query_maxpop);
         wave_add(&counters->wave_queries, c_wave_queries);
     }
 }

@@ -9,3 +9,8 @@ d = st.as_dict(); q = d["queries"]
 print(d)
 print("per query: lane candidates %.2f, wave entries per wave-query %.1f (of %d tests), lanes per entry %.2f" % (
     d["cand_lanes"] / q, d["cand_waves"] / (q / 64), sc.info.num_prims, d["cand_lanes"] / d["cand_waves"]))
+wq = d["wave_queries"]
+print("culling: groups visited per wave-query %.2f (lane mean %.2f), clusters visited per wave-query %.2f (lane mean %.2f), lanes per wave-query %.1f" % (
+    d["groups_visited"] / wq, d["lane_groups"] / q, d["clusters_visited"] / wq, d["lane_clusters"] / q, q / wq))
+print("max over lanes of needed clusters: per visited group %.2f (union %.2f), per wave-query %.2f (union %.2f)" % (
+    d["group_maxpop"] / d["groups_visited"], d["clusters_visited"] / d["groups_visited"], d["query_maxpop"] / wq, d["clusters_visited"] / wq))
