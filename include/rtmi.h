@@ -232,6 +232,8 @@ typedef struct rt_stats {
     uint64_t lane_groups;            /* culling: outer boxes that passed, per LANE */
     uint64_t group_maxpop;           /* culling: max over lanes of needed clusters, summed over visited groups */
     uint64_t query_maxpop;           /* culling: max over lanes of needed clusters, summed over wave-queries */
+    uint64_t cycles[6];              /* shader-clock time per main-loop section, summed over waves: refill, prefix
+                                        spheres, culled spheres + rects + cylinders, shading, accumulation, loop control */
     int32_t cull_prefix, cull_clusters, cull_groups, cull_cluster_size; /* table geometry */
 } rt_stats;
 

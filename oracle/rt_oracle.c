@@ -473,6 +473,11 @@ static ray_t camera_get_ray(const rto_scene *sc, float s, float t, rng_t *g) {
  * constant background.  With no emissive material and the sky gradient this IS the
  * CPU function: L stays 0 until the miss, where L = 0 + beta*sky = sky*ret; an
  * absorbed or depth-exhausted path returns 0. */
+/* debugging aid for the tests: when set, ray_color records every query of the calling thread
+ * as 8 floats (origin, direction, hit t or -1, hit flag) */
+static __thread float *g_trace;
+static __thread int g_trace_n, g_trace_max;
+
 static vec3 ray_color(const rto_scene *s, ray_t now, int depth, rng_t *g, rto_counts *cnt,
                       int *queries) {
     vec3 beta = v3(1.0f, 1.0f, 1.0f); /* `ret` / accumulated_attenuation */
@@ -480,7 +485,14 @@ static vec3 ray_color(const rto_scene *s, ray_t now, int depth, rng_t *g, rto_co
     while (depth > 0) {
         hit_record rec;
         ++*queries;
-        if (world_hit(s, &now, 0.001f, INFINITY, &rec, cnt)) {
+        const int did_hit = world_hit(s, &now, 0.001f, INFINITY, &rec, cnt);
+        if (g_trace && g_trace_n < g_trace_max) {
+            float *t = g_trace + 8 * g_trace_n++;
+            t[0] = now.orig.x, t[1] = now.orig.y, t[2] = now.orig.z;
+            t[3] = now.dir.x, t[4] = now.dir.y, t[5] = now.dir.z;
+            t[6] = did_hit ? rec.t : -1.0f, t[7] = (float)did_hit;
+        }
+        if (did_hit) {
             const rto_material *m = &s->mats[rec.material];
             ray_t scattered;
             vec3 attenuation;
@@ -539,6 +551,16 @@ int rto_sample(const rto_scene *s, uint64_t seed, int x, int y, int sample, floa
         counts->rng_draws += g.draws;
     }
     return queries;
+}
+
+/* rto_sample + the list of its closest-hit queries (8 floats each, see g_trace); returns the
+ * number of queries recorded */
+int rto_trace_sample(const rto_scene *s, uint64_t seed, int x, int y, int sample, float rgb[3],
+                     float *queries8, int max_queries) {
+    g_trace = queries8, g_trace_n = 0, g_trace_max = max_queries;
+    rto_sample(s, seed, x, y, sample, rgb, 0);
+    g_trace = 0;
+    return g_trace_n;
 }
 
 static void counts_add(rto_counts *a, const rto_counts *b) {

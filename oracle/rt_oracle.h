@@ -83,6 +83,8 @@ int rto_sample(const rto_scene *s, uint64_t seed, int x, int y, int sample, floa
 /* rows [y0, y1), samples [sample_first, sample_first+sample_count), summed in
  * chunks of spp_chunk (0 = one chunk); writes rgb_sum[(y*W+x)*3+c] of a full
  * W*H image buffer.  threads <= 0 -> all cores (OpenMP). counts may be NULL. */
+int rto_trace_sample(const rto_scene *s, uint64_t seed, int x, int y, int sample, float rgb[3],
+                     float *queries8, int max_queries);
 int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_first,
                int sample_count, int spp_chunk, float *rgb_sum, rto_counts *counts, int threads);
 

@@ -103,14 +103,15 @@ class Stats(C.Structure):
         ("misses", C.c_uint64), ("scatter", C.c_uint64 * 4), ("rng_draws", C.c_uint64),
         ("cand_lanes", C.c_uint64), ("cand_waves", C.c_uint64), ("clusters_visited", C.c_uint64),
         ("wave_queries", C.c_uint64), ("groups_visited", C.c_uint64), ("lane_clusters", C.c_uint64),
-        ("lane_groups", C.c_uint64), ("group_maxpop", C.c_uint64), ("query_maxpop", C.c_uint64),
+        ("lane_groups", C.c_uint64), ("group_maxpop", C.c_uint64), ("query_maxpop", C.c_uint64), ("cycles", C.c_uint64 * 6),
         ("cull_prefix", C.c_int32),
         ("cull_clusters", C.c_int32), ("cull_groups", C.c_int32), ("cull_cluster_size", C.c_int32),
     ]
 
     def as_dict(self):
-        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "scatter"}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("scatter", "cycles")}
         d["scatter"] = list(self.scatter)
+        d["cycles"] = list(self.cycles)
         return d
 
 

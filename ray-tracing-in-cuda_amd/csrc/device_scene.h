@@ -92,6 +92,7 @@ struct DevCounters {
     unsigned long long clusters_visited;         // culling: clusters whose spheres were tested (per wave)
     unsigned long long groups_visited;           // culling: outer boxes that passed (per wave)
     unsigned long long lane_clusters, lane_groups;  // culling: boxes that passed, per lane
+    unsigned long long cycles[6];  // shader-clock time per main-loop section, summed over waves
     unsigned long long group_maxpop, query_maxpop;  // culling: max over lanes of needed clusters, per visited group / per wave-query
     unsigned long long wave_queries;             // closest-hit queries executed per wave (loop iterations)
 };

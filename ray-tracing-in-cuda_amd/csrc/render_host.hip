@@ -651,6 +651,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->lane_groups = h.lane_groups;
             stats->group_maxpop = h.group_maxpop;
             stats->query_maxpop = h.query_maxpop;
+            for (int i = 0; i < 6; ++i) stats->cycles[i] = h.cycles[i];
             stats->wave_queries = h.wave_queries;
             stats->cull_prefix = P.np, stats->cull_clusters = P.ncl, stats->cull_groups = P.ngr;
             stats->cull_cluster_size = RT_CLUSTER;

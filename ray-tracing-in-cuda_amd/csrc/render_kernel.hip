@@ -115,7 +115,10 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 // CULL:     after the always-tested big spheres, clusters of 8 spheres are visited only if some
 //           lane's ray passes the cluster's (inflated) bounding box: slab test of aabb.hpp:15-29
 //           + __any.  Conservative, so results are unchanged; fewer tests are executed.
-template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, bool CULL>
+//           2 (default): every lane collects the clusters ITS ray reaches in a bit mask and then walks its
+//           own list (per-lane LDS addresses), so a wave spends max-over-lanes instead of union-over-lanes
+//           cluster visits; 1: the whole wave visits every cluster some lane voted for; 0: no culling
+template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
                                                      unsigned int *__restrict__ queue,
@@ -140,6 +143,17 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
     uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0;
     uint32_t c_cand = 0, c_cand_wave = 0, c_clusters = 0, c_groups = 0, c_wave_queries = 0, c_lane_clusters = 0, c_lane_groups = 0, c_group_maxpop = 0, c_query_maxpop = 0;
+    // COUNT: shader-clock time of the main loop's sections, per wave (refill, prefix spheres, culled spheres +
+    // rects + cylinders, shading, pixel accumulation, loop control)
+    unsigned long long cyc[6] = {0, 0, 0, 0, 0, 0}, tmark = 0;
+    auto tick = [&](int section) {
+        if (COUNT) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            cyc[section] += now - tmark;
+            tmark = now;
+        }
+    };
+    if (COUNT) tmark = __builtin_amdgcn_s_memtime();
 
     // ---- persistent waves, streaming work items.  The grid only fills the chip; every wave pulls
     // (8x8 tile, sample chunk) work items from one global counter until it runs dry.  A wave does not
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     bool active = false;
 
     for (;;) {
+        tick(5);
         // ---- refill: lanes without a live path take new samples
         // (render()'s sample loop, main.cu:95-101; camera::get_ray camera.h:32-39)
         const bool need = !active;
@@ -295,6 +310,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 if (COUNT) c_samples++;
             }
         }
+        tick(0);
         // the older item retires when its last path has ended
         if (o_busy && __builtin_amdgcn_ballot_w64(active && in_old) == 0ull) {
             flush_tile(o_acc, o_x0, o_band);
@@ -390,11 +406,18 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     RT_SPHERE_TEST(s, i)
                 }
             }
+            tick(1);
             // ---- culling set-up (CULL): aabb::hit (aabb.hpp:15-29) for every live lane, then one wave-wide
             // vote per box; used for the sphere clusters and for each cylinder's bounding box
             // 1-ulp reciprocals are enough here: the box test only has to be conservative, and the
             // margin below is five orders of magnitude larger than their error
-            const float idx = __builtin_amdgcn_rcpf(dx), idy = __builtin_amdgcn_rcpf(dy), idz = __builtin_amdgcn_rcpf(dz);
+            // Clamped to +-1e18: a direction component that is exactly 0 (a fuzz-free mirror produces them)
+            // would give inf, and the fma form below inf - inf = NaN on the face behind the origin, which
+            // min/max then drop together with the slab.  With a huge finite value the axis keeps its
+            // meaning: origin inside the slab -> (-huge, +huge), outside -> both of one sign -> dead.
+            const float idx = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dx), -1e18f, 1e18f);
+            const float idy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dy), -1e18f, 1e18f);
+            const float idz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dz), -1e18f, 1e18f);
             // per-lane box margin covering the fp32 error of the sphere test at this origin's
             // distance (derivation in render_host.hip): two shifted origins, nothing per box
             const float marg = 4e-3f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + P.cull_extent1);
@@ -418,21 +441,63 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), blim), fmaxf(lz, uz));
                 return !(tn > tf);
             };
-            if (CULL) {
-                uint32_t q_mine = 0;  // COUNT: clusters this lane's ray needs in this query
-                auto wave_max = [&](uint32_t v) {
-                    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
-                    return v;
-                };
+            if (CULL == 2) {
+                // windows of 64 clusters (16 outer boxes): one mask bit per cluster
+                for (int g0 = 0; g0 < P.ngr; g0 += 64 / RT_GROUP) {
+                    // phase 1: which clusters can this lane's ray reach?  (wave-uniform box reads)
+                    unsigned long long mine = 0ull;
+                    const int g_end = min(P.ngr, g0 + 64 / RT_GROUP);
+                    for (int g = g0; g < g_end; ++g) {
+                        const bool glive = slab_live(gbox[2 * g], gbox[2 * g + 1]);
+                        if (__builtin_amdgcn_ballot_w64(glive) == 0ull) continue;
+                        if (COUNT) c_groups++, c_lane_groups += glive ? 1u : 0u;
+                        const int nj = min(RT_GROUP, P.ncl - g * RT_GROUP);
+                        uint32_t gm = 0;
+#pragma unroll
+                        for (int j = 0; j < RT_GROUP; ++j) {
+                            if (j < nj) {
+                                const int q = g * RT_GROUP + j;
+                                if (slab_live(box[2 * q], box[2 * q + 1])) gm |= 1u << j;
+                            }
+                        }
+                        if (COUNT) c_lane_clusters += __popc(gm);
+                        mine |= (unsigned long long)gm << (RT_GROUP * (g - g0));
+                    }
+                    if (COUNT) {
+                        uint32_t m = (uint32_t)__popcll(mine);
+                        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+                        if (lane == 0) c_query_maxpop += m;
+                    }
+                    // phase 2: every lane walks its own clusters; lanes that are done wait masked off
+                    while (__builtin_amdgcn_ballot_w64(mine != 0ull) != 0ull) {
+                        if (mine != 0ull) {
+                            const int q = (int)__builtin_ctzll(mine);
+                            mine &= mine - 1ull;
+                            const int base = P.np + RT_CLUSTER * (g0 * RT_GROUP + q);
+#ifdef RT_EXPERIMENT_UNIFORM
+                            const float4 *cs = sph + __builtin_amdgcn_readfirstlane(base);
+#else
+                            const float4 *cs = sph + base;
+#endif
+                            float4 rec[RT_CLUSTER];
+#pragma unroll
+                            for (int k = 0; k < RT_CLUSTER; ++k) rec[k] = cs[k];
+#pragma unroll
+                            for (int k = 0; k < RT_CLUSTER; ++k) RT_SPHERE_TEST(rec[k], base + k)
+                        }
+                        if (COUNT) c_clusters++;
+                    }
+                }
+                blim = best_t * 1.0001f;
+            } else if (CULL == 1) {
                 for (int g = 0; g < P.ngr; ++g) {
-                uint32_t g_mine = 0;
                 const bool glive = slab_live(gbox[2 * g], gbox[2 * g + 1]);
                 if (__builtin_amdgcn_ballot_w64(glive) == 0ull) continue;
                 if (COUNT) c_groups++, c_lane_groups += glive ? 1u : 0u;
                 const int q_end = min(P.ncl, (g + 1) * RT_GROUP);
                 for (int q = g * RT_GROUP; q < q_end; ++q) {
                     const bool live = slab_live(box[2 * q], box[2 * q + 1]);
-                    if (COUNT && live && glive) c_lane_clusters++, q_mine++, g_mine++;
+                    if (COUNT && live) c_lane_clusters++;
                     if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
                         const int base = P.np + RT_CLUSTER * q;
                         const float4 *cs = sph + base;
@@ -445,14 +510,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         if (COUNT) c_clusters++;
                     }
                 }
-                if (COUNT) {
-                    const uint32_t m = wave_max(g_mine);
-                    if (lane == 0) c_group_maxpop += m;
-                }
-                }
-                if (COUNT) {
-                    const uint32_t m = wave_max(q_mine);
-                    if (lane == 0) c_query_maxpop += m;
                 }
             }
 #undef RT_SPHERE_TEST
@@ -544,6 +601,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 if ((int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) == lane) c_wave_queries++;
             }
 
+            tick(2);
             // ---- shade the winner (ray_color body, main.cu:45-65 / main.cpp:22-38)
             bool path_done = false;
             // 1/|d| once per query (metal, dielectric and the sky all normalise the direction)
@@ -695,6 +753,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 path_done = true;
                 if (COUNT) c_misses++;
             }
+            tick(3);
             if (path_done) {  // res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
                 unsigned long long *a = (in_old ? o_acc : c_acc) + cur_p * 3;
                 atomicAdd(a + 0, radiance_to_fixed(L_r));
@@ -702,6 +761,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 atomicAdd(a + 2, radiance_to_fixed(L_b));
                 active = false;
             }
+            tick(4);
         }
     }
 
@@ -729,6 +789,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         wave_add(&counters->lane_groups, c_lane_groups);
         wave_add(&counters->group_maxpop, c_group_maxpop);
         wave_add(&counters->query_maxpop, c_query_maxpop);
+        if (lane == 0)
+            for (int i = 0; i < 6; ++i) atomicAdd(&counters->cycles[i], cyc[i]);
         wave_add(&counters->wave_queries, c_wave_queries);
     }
 }
@@ -744,23 +806,25 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 // launchers used by render_host.hip
 // X(variant id, POOL, PREFETCH, SCALAR, CULL).  0 is the product default; the others are ablations
 // with identical results: bit 0 = no tile pool (strict one-lane-per-pixel), bit 1 = no LDS prefetch,
-// bit 3 = sphere table through the scalar cache instead of LDS, bit 4 = no cluster culling (every
-// sphere tested for every query: the reference's linear hittable_list scan)
-#define RT_VARIANT_TABLE(X)          \
-    X(0, true, true, false, true)    \
-    X(1, false, true, false, true)   \
-    X(2, true, false, false, true)   \
-    X(8, true, true, true, true)     \
-    X(16, true, true, false, false)  \
-    X(17, false, true, false, false) \
-    X(19, false, false, false, false) \
-    X(24, true, true, true, false)
+// bit 3 = sphere table through the scalar cache instead of LDS (wave-level cluster votes), bit 4 = no
+// cluster culling (every sphere tested for every query: the reference's linear hittable_list scan),
+// bit 5 = wave-level cluster votes instead of per-lane cluster lists
+#define RT_VARIANT_TABLE(X)        \
+    X(0, true, true, false, 2)     \
+    X(1, false, true, false, 2)    \
+    X(2, true, false, false, 2)    \
+    X(8, true, true, true, 1)      \
+    X(16, true, true, false, 0)    \
+    X(17, false, true, false, 0)   \
+    X(19, false, false, false, 0)  \
+    X(24, true, true, true, 0)     \
+    X(32, true, true, false, 1)
 void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
                    DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
     const float4 *img = (const float4 *)image;
     const dim3 g(grid), t(256);
     if (counters) {
-        hipLaunchKernelGGL((render_kernel<true, true, true, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
+        hipLaunchKernelGGL((render_kernel<true, true, true, false, 2>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
         return;
     }
     DevCounters *none = nullptr;
@@ -781,7 +845,7 @@ int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes) {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
     if (count) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, true>, 256, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, 2>, 256, lds_bytes);
     } else {
 #define RT_OCC(V, POOL, PRE, SCALAR, CULL) \
     if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL>, 256, lds_bytes);
@@ -805,7 +869,7 @@ void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStr
 }
 
 int set_max_dynamic_lds(size_t bytes) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, true, true, false, true>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, true, true, false, 2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
         return 1;
 #define RT_ATTR(V, POOL, PRE, SCALAR, CULL)                                                            \

@@ -160,6 +160,19 @@ def oracle_sample(scene, seed, x, y, sample):
     return np.array(rgb[:], dtype=np.float32), q
 
 
+def oracle_trace_sample(scene, seed, x, y, sample, max_queries=64):
+    """The closest-hit queries of one sample in the checker: rows of (origin xyz, direction xyz, hit t or -1, hit)."""
+    lib = oracle_lib()
+    osc = scene if isinstance(scene, OracleScene) else OracleScene(scene)
+    rgb = (C.c_float * 3)()
+    buf = np.zeros((max_queries, 8), dtype=np.float32)
+    lib.rto_trace_sample.restype = C.c_int
+    lib.rto_trace_sample.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    n = lib.rto_trace_sample(C.cast(C.byref(osc.c), C.c_void_p), seed, x, y, sample, C.cast(rgb, C.c_void_p),
+                             buf.ctypes.data_as(C.c_void_p), max_queries)
+    return np.array(rgb[:], dtype=np.float32), buf[:n]
+
+
 def oracle_derive_camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist):
     lib = oracle_lib()
     p = _RtoCameraParams()

@@ -127,7 +127,7 @@ def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
     assert np.abs(acc - whole).max() <= 13 * 2.0 ** -24 * max(1.0, acc.max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 8, 16, 17, 19, 24])
+@pytest.mark.parametrize("variant", [0, 1, 2, 8, 16, 17, 19, 24, 32])
 def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir, variant):
     """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
     bit 1: unbatched sphere loop; bit 3: sphere table read through the scalar cache instead of
@@ -269,6 +269,28 @@ def test_full_frame_properties(rtmi, rtcheck):
         assert np.array_equal(full[y0:y0 + 2], ref[y0:y0 + 2])
     mean = full.astype(np.float64).mean() / 2
     assert 0.3 < mean < 0.7 and np.isfinite(full).all() and full.min() >= 0
+
+
+def test_axis_parallel_bounce_is_not_culled(rtmi, rtcheck):
+    """RTIOW 1920x1080, seed 2023, pixel (1745, 128), sample 8: the bounce off a fuzz-free mirror has
+    dy == 0 exactly.  1/dy = inf turned the fma-form slab test (b/d - o/d) into inf - inf = NaN on one
+    face, min/max dropped the NaN together with the whole slab, and the ray skipped the cluster of the
+    sphere it hits (found when every lane started to rely on its own box tests).  The reciprocal is
+    clamped to +-1e18 since."""
+    sc = rtmi.Scene.rtiow(7, 1920, 1080, 1, 50)
+    x, y, smp = 1745, 128, 8
+    osc = rtcheck.OracleScene(sc)
+    ref, queries = rtcheck.oracle_trace_sample(osc, SEED, x, y, smp)
+    assert len(queries) == 3 and queries[1][4] == 0.0 and queries[1][7] == 1.0  # dy == 0, and it hits
+    rows = {}
+    for variant in (0, 1, 32, 16):
+        o = rtmi.Opts(seed=SEED, variant=variant, sample_first=smp, sample_count=1, tile_rows=1, tile_first=y,
+                      tile_stride=100000)
+        rows[variant] = sc.render(o)
+        assert rows[variant].shape == (1, 1920, 3)
+        assert np.array_equal(rows[variant][0, x], ref), variant
+    for variant in (0, 1, 32):
+        assert np.array_equal(rows[variant], rows[16])
 
 
 def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):

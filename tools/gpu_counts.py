@@ -14,3 +14,6 @@ print("culling: groups visited per wave-query %.2f (lane mean %.2f), clusters vi
     d["groups_visited"] / wq, d["lane_groups"] / q, d["clusters_visited"] / wq, d["lane_clusters"] / q, q / wq))
 print("max over lanes of needed clusters: per visited group %.2f (union %.2f), per wave-query %.2f (union %.2f)" % (
     d["group_maxpop"] / d["groups_visited"], d["clusters_visited"] / d["groups_visited"], d["query_maxpop"] / wq, d["clusters_visited"] / wq))
+cy = d["cycles"]; tot = sum(cy) or 1
+names = ["refill", "prefix spheres", "culled spheres/rects/cylinders", "shading", "accumulate", "loop control"]
+print("main-loop time shares (count kernel, s_memtime per wave): " + ", ".join(f"{n} {100*c/tot:.1f}%" for n, c in zip(names, cy)))

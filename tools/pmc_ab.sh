@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for V in $VARS; do
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/v${V}_a -- python3 $R/tools/gpu_sweep.py $SPP $CH $V > $OUT/v${V}_a.log 2>&1 || { echo fail a $V; tail -3 $OUT/v${V}_a.log; }
-  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH --output-format csv -d $OUT/v${V}_b -- python3 $R/tools/gpu_sweep.py $SPP $CH $V > $OUT/v${V}_b.log 2>&1 || { echo fail b $V; tail -3 $OUT/v${V}_b.log; }
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/v${V}_b -- python3 $R/tools/gpu_sweep.py $SPP $CH $V > $OUT/v${V}_b.log 2>&1 || { echo fail b $V; tail -3 $OUT/v${V}_b.log; }
   rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/v${V}_c -- python3 $R/tools/gpu_sweep.py $SPP $CH $V > $OUT/v${V}_c.log 2>&1 || { echo fail c $V; tail -3 $OUT/v${V}_c.log; }
 done
 python3 - <<PY
