@@ -474,16 +474,16 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                             const int q = (int)__builtin_ctzll(mine);
                             mine &= mine - 1ull;
                             const int base = P.np + RT_CLUSTER * (g0 * RT_GROUP + q);
-#ifdef RT_EXPERIMENT_UNIFORM
-                            const float4 *cs = sph + __builtin_amdgcn_readfirstlane(base);
-#else
                             const float4 *cs = sph + base;
-#endif
-                            float4 rec[RT_CLUSTER];
+                            // four records at a time: eight in flight cost 20 spilled VGPRs at 6 waves/SIMD
 #pragma unroll
-                            for (int k = 0; k < RT_CLUSTER; ++k) rec[k] = cs[k];
-#pragma unroll
-                            for (int k = 0; k < RT_CLUSTER; ++k) RT_SPHERE_TEST(rec[k], base + k)
+                            for (int h = 0; h < RT_CLUSTER; h += 4) {
+                                const float4 r0 = cs[h], r1 = cs[h + 1], r2 = cs[h + 2], r3 = cs[h + 3];
+                                RT_SPHERE_TEST(r0, base + h)
+                                RT_SPHERE_TEST(r1, base + h + 1)
+                                RT_SPHERE_TEST(r2, base + h + 2)
+                                RT_SPHERE_TEST(r3, base + h + 3)
+                            }
                         }
                         if (COUNT) c_clusters++;
                     }
