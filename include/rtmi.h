@@ -39,7 +39,8 @@ typedef enum rt_status {
     RT_ERR_JSON = 3,    /* malformed JSON text                               */
     RT_ERR_SCENE = 4,   /* well-formed JSON, invalid scene (unknown type...) */
     RT_ERR_HIP = 5,     /* HIP runtime / device error                        */
-    RT_ERR_LIMIT = 6    /* scene does not fit the kernel's LDS staging       */
+    RT_ERR_LIMIT = 6    /* an explicitly requested LDS-table kernel variant cannot hold the scene,
+                           or the work-item count overflows (the default variant has no scene limit) */
 } rt_status;
 
 /* ---- table records (what the scene flattens to; also what the checker in
@@ -212,7 +213,9 @@ typedef struct rt_opts {
     int32_t sample_count; /* 0 -> scene spp                                    */
     uint32_t variant;     /* 0 = default kernel; ablation builds (same results): bit 0 strict
                              one-lane-per-pixel, bit 1 no LDS prefetch, bit 3 scalar-cache table,
-                             bit 4 no cluster culling (linear scan of every sphere) */
+                             bit 4 no cluster culling (linear scan of every sphere), bit 5 wave-level
+                             cluster votes; 40 = default algorithm with all tables in global memory
+                             (what variant 0 switches to for scenes too large for LDS) */
 } rt_opts;
 
 typedef struct rt_stats {

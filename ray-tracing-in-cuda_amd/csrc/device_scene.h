@@ -70,6 +70,7 @@ struct RenderParams {
     int32_t ncl;             // clusters of 8 slots after the prefix, each with a bounding box
     int32_t off_box;         // 2 float4 per cluster: {min.xyz,_}, {max.xyz,_}
     int32_t ngr, off_gbox;   // outer boxes over RT_GROUP consecutive clusters
+    int32_t nwin, off_wbox;  // window boxes over 64 consecutive clusters (64 / RT_GROUP outer boxes)
     int32_t off_cbox;        // 2 float4 per cylinder: world-space bounding box of the open tube
     float cull_extent1;      // 1 + max |coordinate| of the clustered spheres (per-lane box margin, see packer)
     int32_t hot_vec4;        // float4 count of the hot part (LDS bytes / 16)

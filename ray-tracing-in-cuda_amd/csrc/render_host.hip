@@ -17,6 +17,9 @@
 #include "device_scene.h"
 #include "scene.hpp"
 
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 6
+#endif
 namespace rtmi {
 
 void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
@@ -149,6 +152,11 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     L.ngr = n_groups;
     L.off_gbox = off;
     off += 2 * n_groups;
+    const int groups_per_window = 64 / RT_GROUP;  // one 64-bit cluster mask per window in the kernel
+    const int n_windows = (n_groups + groups_per_window - 1) / groups_per_window;
+    L.nwin = n_windows;
+    L.off_wbox = off;
+    off += 2 * n_windows;
     L.off_rect_hot = off;
     off += 2 * L.nr;
     L.off_cyl_hot = off;
@@ -244,6 +252,14 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         for (int q = g * RT_GROUP; q < std::min(n_clusters, (g + 1) * RT_GROUP); ++q) {
             const float *b = rec4(L.off_box + 2 * q);
             for (int a = 0; a < 3; ++a) gb[a] = std::min(gb[a], b[a]), gb[4 + a] = std::max(gb[4 + a], b[4 + a]);
+        }
+    }
+    for (int w = 0; w < n_windows; ++w) {  // third level (big scenes): union of the window's outer boxes
+        float *wb = rec4(L.off_wbox + 2 * w);
+        for (int a = 0; a < 3; ++a) wb[a] = INFINITY, wb[4 + a] = -INFINITY;
+        for (int g = w * groups_per_window; g < std::min(n_groups, (w + 1) * groups_per_window); ++g) {
+            const float *b = rec4(L.off_gbox + 2 * g);
+            for (int a = 0; a < 3; ++a) wb[a] = std::min(wb[a], b[a]), wb[4 + a] = std::max(wb[4 + a], b[4 + a]);
         }
     }
     for (int k = 0; k < L.nr; ++k) {
@@ -452,7 +468,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         return RT_ERR_ARG;
     }
 
-    const unsigned variant = o ? o->variant : 0;
+    unsigned variant = o ? o->variant : 0;
     if (!variant_exists(variant)) {
         set_error("unknown kernel variant %u", variant);
         return RT_ERR_ARG;
@@ -548,11 +564,21 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     P.tiles_x = (s.width + 7) / 8;
     P.bands = (sh.local_rows + 7) / 8;
 
-    const size_t lds_bytes = (size_t)P.hot_vec4 * 16 + 4 * 2 * 192 * sizeof(unsigned long long);
+    // LDS per workgroup: the hot tables (unless the variant reads them from global memory: bit 3) + two
+    // tile accumulators per wave.  The default kernel keeps the tables in LDS while that still leaves room
+    // for the kernel's full occupancy (RT_WAVES_PER_SIMD workgroups per CU: RTIOW's 484 spheres 249 vs 253
+    // ms); larger scenes run the same algorithm over global memory (variant 40: 1000 spheres 6.4 vs 6.9 ms,
+    // 4000 spheres 20 vs 66 ms), which has no size limit.
+    const size_t acc_lds = 4 * 2 * 192 * sizeof(unsigned long long);
+    const size_t hot_bytes = (size_t)P.hot_vec4 * 16;
+    static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
+                                                                             : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;
+    if (variant == 0 && hot_bytes > global_threshold) variant = 40;
+    const size_t lds_bytes = ((variant & 8u) ? 0 : hot_bytes) + acc_lds;
     if (lds_bytes > 160 * 1024) {
-        set_error("scene needs %zu bytes of LDS per workgroup (limit 163840): too many primitives for the "
-                  "LDS-resident list",
-                  lds_bytes);
+        set_error("kernel variant %u keeps the scene tables in LDS and this scene needs %zu bytes per workgroup "
+                  "(limit 163840); use the default variant",
+                  variant, lds_bytes);
         return RT_ERR_LIMIT;
     }
     if (lds_bytes > 64 * 1024 && set_max_dynamic_lds(lds_bytes)) {

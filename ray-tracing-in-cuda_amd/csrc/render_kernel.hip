@@ -110,7 +110,10 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 //           / false: a lane only renders samples of its own pixel
 // PREFETCH: sphere records are read from LDS one batch of four ahead (default)
 //           / false: one record per iteration, waited for in place
-// SCALAR:   the sphere table is read with wave-uniform loads from global memory (scalar
+// SCALAR:   nothing is staged in LDS: every table is read from global memory -- wave-uniform reads through
+//           the scalar cache (SGPR operands), per-lane reads through the vector L1/L2.  The mode for scenes
+//           whose tables would crowd out occupancy or not fit the 160 KB at all (and an ablation).  Was:
+//           the sphere table is read with wave-uniform loads from global memory (scalar
 //           cache -> SGPR operands) instead of LDS broadcast reads (experiment)
 // CULL:     after the always-tested big spheres, clusters of 8 spheres are visited only if some
 //           lane's ray passes the cluster's (inflated) bounding box: slab test of aabb.hpp:15-29
@@ -125,18 +128,20 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                                                      DevCounters *__restrict__ counters) {
     extern __shared__ float4 lds[];
     // stage the hot tables (hittable_list contents) into LDS
-    for (int i = threadIdx.x; i < P.hot_vec4; i += 256) lds[i] = image[i];
+    const int staged = SCALAR ? 0 : P.hot_vec4;
+    for (int i = threadIdx.x; i < staged; i += 256) lds[i] = image[i];
     // per-wave tile accumulators (two: current and older work item): 64 pixels x rgb, 64-bit fixed point
-    unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + P.hot_vec4);
+    unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + staged);
     for (int i = threadIdx.x; i < 4 * 2 * 64 * 3; i += 256) tile_acc[i] = 0ull;
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned long long *my_acc = tile_acc + wave * 384;
     const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
-    const float4 *sph = SCALAR ? image : lds;
-    const float4 *rect = lds + P.off_rect_hot;
-    const float4 *cyl = lds + P.off_cyl_hot;
+    const float4 *hot = SCALAR ? image : lds;
+    const float4 *sph = hot;
+    const float4 *rect = hot + P.off_rect_hot;
+    const float4 *cyl = hot + P.off_cyl_hot;
     const int ns = P.ns, nr = P.nr, nc = P.nc;
     const float wm1 = (float)(P.width - 1), hm1 = (float)(P.height - 1);
 
@@ -426,8 +431,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             // magnitude inside the margin.
             const float nxm = -(ox + marg) * idx, nym = -(oy + marg) * idy, nzm = -(oz + marg) * idz;
             const float nxp = -(ox - marg) * idx, nyp = -(oy - marg) * idy, nzp = -(oz - marg) * idz;
-            const float4 *box = (SCALAR ? image : lds) + P.off_box;
-            const float4 *gbox = (SCALAR ? image : lds) + P.off_gbox;
+            const float4 *box = hot + P.off_box;
+            const float4 *gbox = hot + P.off_gbox;
             // best_t (1 + 1e-4), refreshed whenever spheres have been tested (a stale, larger value only
             // culls less)
             float blim = best_t * 1.0001f;
@@ -444,6 +449,12 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             if (CULL == 2) {
                 // windows of 64 clusters (16 outer boxes): one mask bit per cluster
                 for (int g0 = 0; g0 < P.ngr; g0 += 64 / RT_GROUP) {
+                    // big scenes: one box around the whole window first (third level of the hierarchy)
+                    if (P.nwin > 1) {
+                        const float4 *wb = hot + P.off_wbox + 2 * (g0 / (64 / RT_GROUP));
+                        if (__builtin_amdgcn_ballot_w64(slab_live(wb[0], wb[1])) == 0ull) continue;
+                        blim = best_t * 1.0001f;  // what the previous windows found tightens this one
+                    }
                     // phase 1: which clusters can this lane's ray reach?  (wave-uniform box reads)
                     unsigned long long mine = 0ull;
                     const int g_end = min(P.ngr, g0 + 64 / RT_GROUP);
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 if (CULL) {
                     blim = best_t * 1.0001f;  // the cylinder's world-space box, same margin (the object-space quadratic has the
                              // same error structure as the sphere test: ~1e-3 |o| in space)
-                    const float4 *cb = lds + P.off_cbox + 2 * k;
+                    const float4 *cb = hot + P.off_cbox + 2 * k;
                     if (__builtin_amdgcn_ballot_w64(slab_live(cb[0], cb[1])) == 0ull) continue;
                 }
                 const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2], pr = cyl[4 * k + 3];
@@ -808,7 +819,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 // with identical results: bit 0 = no tile pool (strict one-lane-per-pixel), bit 1 = no LDS prefetch,
 // bit 3 = sphere table through the scalar cache instead of LDS (wave-level cluster votes), bit 4 = no
 // cluster culling (every sphere tested for every query: the reference's linear hittable_list scan),
-// bit 5 = wave-level cluster votes instead of per-lane cluster lists
+// bit 5 = wave-level cluster votes instead of per-lane cluster lists; 40 = the default algorithm with all tables in
+// global memory (chosen automatically for scenes too large for LDS)
 #define RT_VARIANT_TABLE(X)        \
     X(0, true, true, false, 2)     \
     X(1, false, true, false, 2)    \
@@ -818,13 +830,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
     X(17, false, true, false, 0)   \
     X(19, false, false, false, 0)  \
     X(24, true, true, true, 0)     \
-    X(32, true, true, false, 1)
+    X(32, true, true, false, 1)    \
+    X(40, true, true, true, 2)
 void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
                    DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
     const float4 *img = (const float4 *)image;
     const dim3 g(grid), t(256);
     if (counters) {
-        hipLaunchKernelGGL((render_kernel<true, true, true, false, 2>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
+        if (variant == 40) hipLaunchKernelGGL((render_kernel<true, true, true, true, 2>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
+        else hipLaunchKernelGGL((render_kernel<true, true, true, false, 2>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
         return;
     }
     DevCounters *none = nullptr;
@@ -845,7 +859,8 @@ int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes) {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
     if (count) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, 2>, 256, lds_bytes);
+        if (variant == 40) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, true, 2>, 256, lds_bytes);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, 2>, 256, lds_bytes);
     } else {
 #define RT_OCC(V, POOL, PRE, SCALAR, CULL) \
     if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL>, 256, lds_bytes);

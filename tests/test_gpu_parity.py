@@ -127,7 +127,7 @@ def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
     assert np.abs(acc - whole).max() <= 13 * 2.0 ** -24 * max(1.0, acc.max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 8, 16, 17, 19, 24, 32])
+@pytest.mark.parametrize("variant", [0, 1, 2, 8, 16, 17, 19, 24, 32, 40])
 def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir, variant):
     """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
     bit 1: unbatched sphere loop; bit 3: sphere table read through the scalar cache instead of
@@ -236,9 +236,30 @@ def test_error_behaviour(rtmi, scenes_dir, golden_dir):
     m = big.lambertian((0.5, 0.5, 0.5))
     for i in range(11000):  # 11000 x 16 B > 160 KiB of LDS
         big.sphere((i * 0.001, 0, -i), 0.5, m)
+    # the default kernel switches to global-memory tables; variants that keep the tables in LDS cannot
+    assert big.render().shape == (16, 16, 3)
     with pytest.raises(rtmi.RtmiError) as e:
-        big.render()
+        big.render(rtmi.Opts(variant=32))
     assert e.value.status == 6 and "LDS" in str(e.value)
+
+
+def test_scene_too_large_for_lds_uses_global_tables(rtmi, rtcheck):
+    """20000 spheres (320 KB of sphere records alone): the default kernel reads its tables from global
+    memory (three box levels, per-lane cluster lists) and still equals the CPU checker bit for bit; the
+    same kernel forced on a small scene equals the LDS-resident one."""
+    sc = rtmi.Scene.new(40, 24, 2, 12)
+    sc.camera((0, 6, 30), (0, 0, 0), (0, 1, 0), 40.0)
+    sc.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
+    rng = np.random.default_rng(9)
+    mats = [sc.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(6)] + [sc.metal((0.8, 0.8, 0.8), 0.0), sc.dielectric(1.5)]
+    sc.sphere((0, -1010, 0), 1000.0, mats[0])
+    for i in range(20000):
+        sc.sphere(rng.uniform(-10, 10, 3), float(rng.uniform(0.05, 0.2)), mats[i % len(mats)])
+    st = sc.count(rtmi.Opts(seed=SEED))
+    assert st.cull_clusters > 64 * 30  # far more clusters than one 64-cluster window
+    _assert_same(rtmi, rtcheck, sc)
+    small = rtmi.Scene.rtiow(7, 96, 54, 4, 50)
+    assert np.array_equal(small.render(rtmi.Opts(seed=SEED, variant=40)), small.render(rtmi.Opts(seed=SEED)))
 
 
 def test_many_spheres_above_64k_lds(rtmi, rtcheck):
@@ -249,7 +270,9 @@ def test_many_spheres_above_64k_lds(rtmi, rtcheck):
     mats = [sc.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(8)] + [sc.metal((0.8, 0.8, 0.8), 0.1), sc.dielectric(1.5)]
     for i in range(5000):
         sc.sphere(rng.uniform(-6, 6, 3), float(rng.uniform(0.05, 0.2)), mats[i % len(mats)])
-    _assert_same(rtmi, rtcheck, sc)
+    _assert_same(rtmi, rtcheck, sc)              # default: global-memory tables at this size
+    _assert_same(rtmi, rtcheck, sc, variant=32)  # tables in LDS (105 KB: the raised dynamic-LDS limit)
+    _assert_same(rtmi, rtcheck, sc, variant=2)   # per-lane lists over LDS tables
 
 
 def test_full_frame_properties(rtmi, rtcheck):

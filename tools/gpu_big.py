@@ -1,0 +1,33 @@
+"""Scene-size sweep: N random small spheres over a ground sphere, default kernel (LDS tables or, above the
+threshold, global-memory tables) -- kernel time, which variant ran, and equality with the linear scan on
+a few rows.  RTMI_GLOBAL_TABLE_BYTES=<bytes> moves the threshold (read once per process)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+rtmi = load_package()
+sizes = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1000", "2000", "4000", "8000", "20000", "100000"])]
+W, H, SPP = 1280, 720, 16
+for n in sizes:
+    rng = np.random.default_rng(n)
+    half = 6.0 * (n / 5000.0) ** (1.0 / 3.0)
+    sc = rtmi.Scene.new(W, H, SPP, 20)
+    sc.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
+    sc.camera((0, half * 0.6, 3.2 * half), (0, 0, 0), (0, 1, 0), 35.0)
+    mats = [sc.lambertian(sc.solid_color(tuple(rng.uniform(0.1, 0.9, 3)))) for _ in range(6)]
+    mats += [sc.metal(tuple(rng.uniform(0.5, 1.0, 3)), 0.1), sc.dielectric(1.5)]
+    sc.sphere((0, -1000 - half, 0), 1000.0, mats[0])
+    cen = rng.uniform(-half, half, (n, 3)); rad = rng.uniform(0.05, 0.2, n)
+    for i in range(n):
+        sc.sphere(tuple(cen[i]), float(rad[i]), mats[i % len(mats)])
+    ts = []
+    for rep in range(3):
+        st = rtmi.Stats(); img = sc.render(rtmi.Opts(seed=1), st); ts.append(st.kernel_ms)
+    cst = sc.count(rtmi.Opts(seed=1))
+    # a few rows against the linear scan (no culling): must be identical
+    o = rtmi.Opts(seed=1, tile_rows=4, tile_first=60, tile_stride=100000)
+    same = np.array_equal(sc.render(o), sc.render(rtmi.Opts(seed=1, tile_rows=4, tile_first=60, tile_stride=100000, variant=16))) if n <= 4000 else None
+    print(f"n={n}: {min(ts):.2f} ms ({W*H*SPP/min(ts)/1e3:.0f} Msamples/s), clusters {cst.cull_clusters}, "
+          f"wave cluster visits/query {cst.clusters_visited/max(1,cst.wave_queries):.1f}, groups passed/query {cst.groups_visited/max(1,cst.wave_queries):.1f}, "
+          f"rows equal linear scan: {same}", flush=True)
