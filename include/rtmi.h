@@ -238,6 +238,8 @@ typedef struct rt_stats {
     uint64_t cycles[6];              /* shader-clock time per main-loop section, summed over waves: refill, prefix
                                         spheres, culled spheres + rects + cylinders, shading, accumulation, loop control */
     int32_t cull_prefix, cull_clusters, cull_groups, cull_cluster_size; /* table geometry */
+    double wave_start_spread_us, wave_end_spread_us, wave_span_us; /* first-to-last wave start / exit, first start
+                                        to last exit (s_memrealtime) */
 } rt_stats;
 
 void rt_opts_default(rt_opts *o);

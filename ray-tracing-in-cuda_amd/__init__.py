@@ -106,6 +106,7 @@ class Stats(C.Structure):
         ("lane_groups", C.c_uint64), ("group_maxpop", C.c_uint64), ("query_maxpop", C.c_uint64), ("cycles", C.c_uint64 * 6),
         ("cull_prefix", C.c_int32),
         ("cull_clusters", C.c_int32), ("cull_groups", C.c_int32), ("cull_cluster_size", C.c_int32),
+        ("wave_start_spread_us", C.c_double), ("wave_end_spread_us", C.c_double), ("wave_span_us", C.c_double),
     ]
 
     def as_dict(self):

@@ -93,6 +93,11 @@ struct DevCounters {
     unsigned long long clusters_visited;         // culling: clusters whose spheres were tested (per wave)
     unsigned long long groups_visited;           // culling: outer boxes that passed (per wave)
     unsigned long long lane_clusters, lane_groups;  // culling: boxes that passed, per lane
+    unsigned long long t_start_min, t_start_max, t_end_min, t_end_max;  // s_memrealtime (100 MHz) of wave starts / exits
+    unsigned long long t_qe_min, t_qe_max;  // when a wave first found the queue empty
+    unsigned int drain_hist[32];            // waves by time from queue-empty to exit, 50 us bins
+    unsigned int qe_hist[1024];             // waves by time from their start to queue-empty, 64 us bins
+    unsigned int exit_hist[1024];           // waves by time from their start to exit, 64 us bins
     unsigned long long cycles[6];  // shader-clock time per main-loop section, summed over waves
     unsigned long long group_maxpop, query_maxpop;  // culling: max over lanes of needed clusters, per visited group / per wave-query
     unsigned long long wave_queries;             // closest-hit queries executed per wave (loop iterations)

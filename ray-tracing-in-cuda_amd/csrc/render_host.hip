@@ -608,6 +608,10 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         if (!ent->d_counters) HIP_TRY(hipMalloc((void **)&ent->d_counters, sizeof(DevCounters)));
         d_cnt = ent->d_counters;
         HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(DevCounters), stream));
+        // the two minima start at all-ones
+        HIP_TRY(hipMemsetAsync(&d_cnt->t_start_min, 0xff, sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(&d_cnt->t_end_min, 0xff, sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(&d_cnt->t_qe_min, 0xff, sizeof(unsigned long long), stream));
     }
     if (stats) HIP_TRY(hipEventRecord(ev1, stream));
 
@@ -678,6 +682,22 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->group_maxpop = h.group_maxpop;
             stats->query_maxpop = h.query_maxpop;
             for (int i = 0; i < 6; ++i) stats->cycles[i] = h.cycles[i];
+            stats->wave_start_spread_us = (double)(h.t_start_max - h.t_start_min) * 0.01;
+            stats->wave_end_spread_us = (double)(h.t_end_max - h.t_end_min) * 0.01;
+            stats->wave_span_us = (double)(h.t_end_max - h.t_start_min) * 0.01;
+            if (getenv("RTMI_DEBUG_DRAIN")) {
+                fprintf(stderr, "queue-empty seen over %.1f us; first exit %.1f us after the first queue-empty; drain histogram (50 us bins):",
+                        (double)(h.t_qe_max - h.t_qe_min) * 0.01, (double)(h.t_end_min - h.t_qe_min) * 0.01);
+                for (int i = 0; i < 32; ++i) fprintf(stderr, " %u", h.drain_hist[i]);
+                fprintf(stderr, "\nwaves by time from start to queue-empty (64 us bins, first nonzero bin on):");
+                int first = 0;
+                while (first < 1023 && !h.qe_hist[first]) ++first;
+                fprintf(stderr, " [bin %d]", first);
+                for (int i = first; i < 1024 && i < first + 60; ++i) fprintf(stderr, " %u", h.qe_hist[i]);
+                fprintf(stderr, "\nwaves by time from start to exit (same bins):");
+                for (int i = first; i < 1024 && i < first + 60; ++i) fprintf(stderr, " %u", h.exit_hist[i]);
+                fprintf(stderr, "\n");
+            }
             stats->wave_queries = h.wave_queries;
             stats->cull_prefix = P.np, stats->cull_clusters = P.ncl, stats->cull_groups = P.ngr;
             stats->cull_cluster_size = RT_CLUSTER;

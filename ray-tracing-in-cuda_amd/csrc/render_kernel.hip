@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     uint32_t c_cand = 0, c_cand_wave = 0, c_clusters = 0, c_groups = 0, c_wave_queries = 0, c_lane_clusters = 0, c_lane_groups = 0, c_group_maxpop = 0, c_query_maxpop = 0;
     // COUNT: shader-clock time of the main loop's sections, per wave (refill, prefix spheres, culled spheres +
     // rects + cylinders, shading, pixel accumulation, loop control)
-    unsigned long long cyc[6] = {0, 0, 0, 0, 0, 0}, tmark = 0;
+    unsigned long long cyc[6] = {0, 0, 0, 0, 0, 0}, tmark = 0, t_qe = 0;
     auto tick = [&](int section) {
         if (COUNT) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         }
     };
     if (COUNT) tmark = __builtin_amdgcn_s_memtime();
+    unsigned long long t_begin = 0;
+    if (COUNT) t_begin = __builtin_amdgcn_s_memrealtime();
+    if (COUNT && lane == 0) {
+        const unsigned long long t = t_begin;
+        atomicMin(&counters->t_start_min, t);
+        atomicMax(&counters->t_start_max, t);
+    }
 
     // ---- persistent waves, streaming work items.  The grid only fills the chip; every wave pulls
     // (8x8 tile, sample chunk) work items from one global counter until it runs dry.  A wave does not
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 item = __builtin_amdgcn_readfirstlane(item);
                 if (item >= (unsigned int)P.num_items) {
                     queue_empty = true;  // the counter only grows: every wave gets here
+                    if (COUNT) t_qe = __builtin_amdgcn_s_memrealtime();
                 } else {
                     if (c_valid) {  // the current item becomes the older one; every live path is its
                         o_x0 = c_x0, o_band = c_band;
@@ -800,8 +808,19 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         wave_add(&counters->lane_groups, c_lane_groups);
         wave_add(&counters->group_maxpop, c_group_maxpop);
         wave_add(&counters->query_maxpop, c_query_maxpop);
-        if (lane == 0)
+        if (lane == 0) {
             for (int i = 0; i < 6; ++i) atomicAdd(&counters->cycles[i], cyc[i]);
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            atomicMin(&counters->t_end_min, t);
+            atomicMax(&counters->t_end_max, t);
+            atomicMin(&counters->t_qe_min, t_qe);
+            atomicMax(&counters->t_qe_max, t_qe);
+            const unsigned long long bin = (t - t_qe) / 5000ull;  // 100 MHz ticks -> 50 us bins
+            atomicAdd(&counters->drain_hist[bin < 31 ? bin : 31], 1u);
+            const unsigned long long b1 = (t_qe - t_begin) / 6400ull, b2 = (t - t_begin) / 6400ull;
+            atomicAdd(&counters->qe_hist[b1 < 1023 ? b1 : 1023], 1u);
+            atomicAdd(&counters->exit_hist[b2 < 1023 ? b2 : 1023], 1u);
+        }
         wave_add(&counters->wave_queries, c_wave_queries);
     }
 }

@@ -35,7 +35,7 @@ def test_struct_layouts_match_checker(rtmi):
     assert rtmi.MATERIAL_DTYPE.itemsize == 28
     assert rtmi.TEXTURE_DTYPE.itemsize == 28
     assert ctypes.sizeof(rtmi.Opts) == 40
-    assert ctypes.sizeof(rtmi.Stats) == 8 * 2 + 4 * 2 + 8 * 5 + 8 * 4 + 8 + 32 + 8 + 16 + 32 + 48
+    assert ctypes.sizeof(rtmi.Stats) == 8 * 2 + 4 * 2 + 8 * 5 + 8 * 4 + 8 + 32 + 8 + 16 + 32 + 48 + 24
 
 
 def test_no_oracle_in_product():

@@ -3,7 +3,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 rtmi = load_package()
-sc = rtmi.Scene.rtiow(7, 1920, 1080, 16, 50)
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+sc = rtmi.Scene.rtiow(7, 1920, 1080, spp, 50)
 st = sc.count(rtmi.Opts(seed=2023))
 d = st.as_dict(); q = d["queries"]
 print(d)
@@ -17,3 +18,5 @@ print("max over lanes of needed clusters: per visited group %.2f (union %.2f), p
 cy = d["cycles"]; tot = sum(cy) or 1
 names = ["refill", "prefix spheres", "culled spheres/rects/cylinders", "shading", "accumulate", "loop control"]
 print("main-loop time shares (count kernel, s_memtime per wave): " + ", ".join(f"{n} {100*c/tot:.1f}%" for n, c in zip(names, cy)))
+print("waves: start spread %.1f us, exit spread %.1f us, first start to last exit %.1f us (count kernel %.2f ms)" % (
+    d["wave_start_spread_us"], d["wave_end_spread_us"], d["wave_span_us"], d["kernel_ms"]))
