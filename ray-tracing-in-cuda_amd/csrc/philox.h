@@ -29,12 +29,12 @@ struct Philox4 {
     uint32_t v[4];
 };
 
-RTMI_HD uint32_t philox_mulhi(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
-#endif
+// 32 x 32 -> 64-bit product as ONE wide multiply (device: v_mad_u64_u32, one quarter-rate instruction
+// instead of v_mul_hi_u32 + v_mul_lo_u32)
+RTMI_HD void philox_mul(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+    const uint64_t p = (uint64_t)a * (uint64_t)b;
+    hi = (uint32_t)(p >> 32);
+    lo = (uint32_t)p;
 }
 
 RTMI_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -43,8 +43,9 @@ RTMI_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
     const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = philox_mulhi(M0, c0), lo0 = M0 * c0;
-        uint32_t hi1 = philox_mulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t hi0, lo0, hi1, lo1;
+        philox_mul(M0, c0, hi0, lo0);
+        philox_mul(M1, c2, hi1, lo1);
         uint32_t n0 = hi1 ^ c1 ^ k0;
         uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0;

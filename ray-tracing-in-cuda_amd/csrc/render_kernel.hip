@@ -102,7 +102,15 @@ __device__ __forceinline__ int list_index_of(const RenderParams &P, const float4
 // NaN -> 0, magnitude clamped to 1e9 (a pixel sum is exact while it stays below 2^31)
 __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
     if (!(fabsf(v) <= 1e9f)) v = (v != v) ? 0.0f : copysignf(1e9f, v);
-    return (unsigned long long)__double2ll_rn((double)v * 4294967296.0);
+    // llrint((double)v * 2^32) without fp64: |v| = hi + frac with hi = trunc(|v|) (v_cvt_u32_f32; the
+    // subtraction of the integer part is exact), frac * 2^32 < 2^32 is exact, and rounding it to nearest
+    // even rounds the whole value to nearest even because hi * 2^32 is an even integer.
+    const float a = fabsf(v);
+    const uint32_t hi = (uint32_t)a;
+    const float frac = a - (float)hi;
+    const uint32_t lo = (uint32_t)rintf(frac * 4294967296.0f);
+    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    return v < 0.0f ? 0ull - m : m;
 }
 
 // ---------------------------------------------------------------- kernel

@@ -76,3 +76,17 @@ def test_png_writer_round_trip(rtmi, tmp_path):
     rows = np.frombuffer(raw, dtype=np.uint8).reshape(37, 1 + 301 * 3)
     assert not rows[:, 0].any()
     np.testing.assert_array_equal(rows[:, 1:].reshape(37, 301, 3), rtmi.quantize_rgb8(img, 5, gamma=False))
+
+
+def test_fixed_point_conversion_without_fp64(tmp_path):
+    """The kernel converts a sample to 64-bit fixed point without fp64 (trunc + exact fraction + v_rndne);
+    tests/fixed_point_check.c restates that expression in C and compares it with the checker's
+    llrint((double)v * 2^32) on every 37th fp32 bit pattern (all 2^32 take 20 s: run it with stride 1)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fixed_point_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(root, "tests", "fixed_point_check.c"), "-lm"],
+                   check=True)
+    r = subprocess.run([exe, "37"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout
+    assert " 0 mismatches" in r.stdout
