@@ -116,6 +116,7 @@ typedef struct rt_scene_info {
     int32_t num_prims, num_materials, num_textures;
     uint32_t flags;
     float background[3];
+    float russian_roulette; /* survival probability per bounce, 0 = off (rt_scene_set_russian_roulette) */
 } rt_scene_info;
 
 typedef struct rt_scene rt_scene; /* opaque; gpu-version/parser.hpp:16-32 `struct scene` */
@@ -127,7 +128,7 @@ typedef struct rt_scene rt_scene; /* opaque; gpu-version/parser.hpp:16-32 `struc
  * camera{lookfrom lookat vup vfov aperture} object.data[] material.data[]
  * texture.data[] [output_file].  Extensions: texture type "checker"
  * {even[3], odd[3]} (texture.cuh:33-57 has the class, the parser lacks it),
- * optional top-level "sky_gradient": bool and "defocus_blur": bool.
+ * optional top-level "sky_gradient": bool, "defocus_blur": bool and "russian_roulette": number in [0, 1].
  * Unknown object/material/texture "type" is a hard error (the reference
  * silently leaves the slot uninitialised). Returns NULL on failure. */
 rt_scene *rt_scene_load_json(const char *path);
@@ -149,6 +150,14 @@ void rt_scene_free(rt_scene *s);
  *      reference classes (the C++ wrappers in rtmi.hpp call these) -------- */
 rt_scene *rt_scene_new(int width, int height, int spp, int max_depth);
 int rt_scene_set_background(rt_scene *s, const float rgb[3], uint32_t flags);
+/* Russian roulette, the reference's 朴素光线追踪/4_0_path_tracing.py:43-46,88 (p_RR = 0.9): before every
+ * closest-hit query the path survives with probability p (one extra draw; a path that does not
+ * survive returns what it has collected so far) and a survivor's throughput is divided by p, so
+ * the estimate stays unbiased (the reference divides after the scatter instead, which leaves the
+ * last segment uncompensated: its images are darker by the factor p).  A non-parity fast mode: it changes which draws a sample
+ * consumes, so images differ from p = 0 by noise, not bit for bit.  p = 0 (default) switches it off;
+ * JSON: top-level "russian_roulette": p. */
+int rt_scene_set_russian_roulette(rt_scene *s, float p);
 /* camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist) camera.cuh:9-15;
  * aspect <= 0 -> width/height, focus_dist <= 0 -> |lookfrom-lookat| (parser.hpp:122-124) */
 int rt_scene_set_camera(rt_scene *s, const float lookfrom[3], const float lookat[3],

@@ -206,6 +206,8 @@ public:
         check(rt_render_hip(s_, &o, img.data(), stats), "render");
         return img;
     }
+    // Russian roulette (4_0_path_tracing.py's p_RR): survival probability per bounce, 0 = off
+    void set_russian_roulette(float p) { check(rt_scene_set_russian_roulette(s_, p), "set_russian_roulette"); }
     // progressive rendering: adds samples [first, first + count) to the caller's exact pixel sums
     // (resized and zeroed when empty) and returns the framebuffer of the updated sums
     std::vector<float> accumulate(std::vector<int64_t> &acc, int first, int count, const rt_opts *opts = nullptr,

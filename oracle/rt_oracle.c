@@ -484,6 +484,16 @@ static vec3 ray_color(const rto_scene *s, ray_t now, int depth, rng_t *g, rto_co
     vec3 L = v3(0.0f, 0.0f, 0.0f);    /* accumulated_color */
     while (depth > 0) {
         hit_record rec;
+        memset(&rec, 0, sizeof rec);
+        /* Russian roulette, 朴素光线追踪/4_0_path_tracing.py:45-46: `if ti.random() > p_RR: break` before
+         * every query (the path returns what it has collected).  A survivor's throughput is divided
+         * by p at once, which compensates everything gathered from this query on; the reference
+         * divides after the scatter (:88), which leaves the segment that ends at a light or at the
+         * background uncompensated -- its images are darker by the factor p. */
+        if (s->rr_p > 0.0f) {
+            if (random_float(g) > s->rr_p) return L;
+            beta = v3(beta.x / s->rr_p, beta.y / s->rr_p, beta.z / s->rr_p);
+        }
         ++*queries;
         const int did_hit = world_hit(s, &now, 0.001f, INFINITY, &rec, cnt);
         if (g_trace && g_trace_n < g_trace_max) {

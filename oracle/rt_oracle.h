@@ -66,6 +66,7 @@ typedef struct rto_scene {
     int32_t num_mats;
     const rto_texture *texs;
     int32_t num_texs;
+    float rr_p; /* Russian-roulette survival probability per bounce, 0 = off */
 } rto_scene;
 
 typedef struct rto_counts {

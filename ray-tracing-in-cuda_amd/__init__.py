@@ -74,7 +74,7 @@ class _Info(C.Structure):
     _fields_ = [
         ("width", C.c_int32), ("height", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32),
         ("num_prims", C.c_int32), ("num_materials", C.c_int32), ("num_textures", C.c_int32),
-        ("flags", C.c_uint32), ("background", C.c_float * 3),
+        ("flags", C.c_uint32), ("background", C.c_float * 3), ("russian_roulette", C.c_float),
     ]
 
 
@@ -161,6 +161,7 @@ _sig("rt_shard_rows", C.c_int, _p, C.POINTER(Opts))
 _sig("rt_shard_global_row", C.c_int, _p, C.POINTER(Opts), C.c_int)
 _sig("rt_render_hip_device", C.c_int, _p, C.POINTER(Opts), _p, _p, C.POINTER(Stats))
 _sig("rt_render_hip", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
+_sig("rt_scene_set_russian_roulette", C.c_int, _p, C.c_float)
 _sig("rt_render_hip_count", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
 _sig("rt_render_hip_accumulate", C.c_int, _p, C.POINTER(Opts), _p, _p, C.POINTER(Stats))
 _sig("rt_acc_to_rgb", None, _p, _p, C.c_size_t)
@@ -181,7 +182,7 @@ C_SYMBOLS = [
     "rt_scene_add_diffuse_light", "rt_scene_add_sphere", "rt_scene_add_rect", "rt_scene_add_cylinder",
     "rt_scene_override", "rt_scene_get_info", "rt_scene_get_camera", "rt_scene_get_prims",
     "rt_scene_get_materials", "rt_scene_get_textures", "rt_shard_rows", "rt_shard_global_row",
-    "rt_render_hip_device", "rt_render_hip", "rt_render_hip_count", "rt_render_hip_accumulate",
+    "rt_render_hip_device", "rt_render_hip", "rt_render_hip_count", "rt_render_hip_accumulate", "rt_scene_set_russian_roulette",
     "rt_acc_to_rgb", "rt_shard_scatter_rows", "rt_write_ppm",
     "rt_quantize_rgb8", "rt_philox4x32_10", "rt_aabb_hit", "rt_sample_stream", "rt_write_png",
     "rt_scene_output_file", "rt_scene_rotate_cylinders", "rt_scene_set_output_file", "rt_scene_dna", "rt_scene_clone",
@@ -250,6 +251,10 @@ class Scene:
     def set_background(self, rgb=(0, 0, 0), sky_gradient=False, defocus_blur=True):
         flags = (FLAG_SKY_GRADIENT if sky_gradient else 0) | (FLAG_DEFOCUS_BLUR if defocus_blur else 0)
         _check(_lib.rt_scene_set_background(self._h, _v3(rgb), flags), "set_background")
+
+    def set_russian_roulette(self, p: float):
+        """Survival probability per bounce (4_0_path_tracing.py's p_RR); 0 switches it off."""
+        _check(_lib.rt_scene_set_russian_roulette(self._h, float(p)), "set_russian_roulette")
 
     def camera(self, lookfrom, lookat, vup, vfov, aspect_ratio=0.0, aperture=0.0, focus_dist=0.0):
         _check(_lib.rt_scene_set_camera(self._h, _v3(lookfrom), _v3(lookat), _v3(vup), vfov, aspect_ratio,

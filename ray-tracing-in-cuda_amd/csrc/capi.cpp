@@ -125,6 +125,17 @@ rt_scene *rt_scene_new(int width, int height, int spp, int max_depth) {
     return s;
 }
 
+int rt_scene_set_russian_roulette(rt_scene *s, float p) {
+    if (bad_scene(s, "rt_scene_set_russian_roulette")) return RT_ERR_ARG;
+    if (!(p >= 0.0f && p <= 1.0f)) {
+        set_error("rt_scene_set_russian_roulette: p = %g is not a probability", (double)p);
+        return RT_ERR_ARG;
+    }
+    s->s.rr_p = p;
+    s->s.touch();
+    return RT_OK;
+}
+
 int rt_scene_set_background(rt_scene *s, const float rgb[3], uint32_t flags) {
     if (bad_scene(s, "rt_scene_set_background")) return RT_ERR_ARG;
     if (rgb) memcpy(s->s.background, rgb, 3 * sizeof(float));
@@ -393,6 +404,7 @@ int rt_scene_get_info(const rt_scene *s, rt_scene_info *out) {
     out->num_textures = (int)s->s.texs.size();
     out->flags = s->s.flags;
     memcpy(out->background, s->s.background, sizeof out->background);
+    out->russian_roulette = s->s.rr_p;
     return RT_OK;
 }
 

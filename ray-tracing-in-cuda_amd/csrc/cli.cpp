@@ -37,7 +37,7 @@ static int usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [-f scene.json | --rtiow] [-w W] [-h H] [-d DEPTH] [-spp N] [-o out.ppm]\n"
             "          [--seed S] [--scene-seed S] [--device N] [--chunk N] [--dump-json file] [--count] [--no-png]\n"
-            "          [--acc-in sums.bin] [--acc-out sums.bin] [--spp-begin FIRST]\n",
+            "          [--acc-in sums.bin] [--acc-out sums.bin] [--spp-begin FIRST] [--rr SURVIVAL_PROBABILITY]\n",
             argv0);
     return 2;
 }
@@ -47,6 +47,7 @@ int main(int argc, char **argv) {
     std::string out_file = "main.ppm";             // main.cu:512
     std::string dump_json, acc_in, acc_out;
     long long spp_begin = -1;
+    double rr = -1.0;  // Russian roulette: keep the scene file's setting
     bool rtiow = false, have_file = false, count = false, no_png = false;
     int w = 0, h = 0, depth = 0, spp = 0, device = 0, chunk = 0;
     unsigned long long seed = 2023;
@@ -73,6 +74,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--acc-in")) acc_in = need("--acc-in");
         else if (!strcmp(argv[i], "--acc-out")) acc_out = need("--acc-out");
         else if (!strcmp(argv[i], "--spp-begin")) spp_begin = atoll(need("--spp-begin"));
+        else if (!strcmp(argv[i], "--rr")) rr = atof(need("--rr"));
         else if (!strcmp(argv[i], "--rtiow")) rtiow = true;
         else if (!strcmp(argv[i], "--count")) count = true;
         else if (!strcmp(argv[i], "--no-png")) no_png = true;
@@ -92,6 +94,10 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (rt_scene_override(sc, w, h, spp, depth) != RT_OK) {
+        fprintf(stderr, "rtmi: %s\n", rt_last_error());
+        return 1;
+    }
+    if (rr >= 0.0 && rt_scene_set_russian_roulette(sc, (float)rr) != RT_OK) {
         fprintf(stderr, "rtmi: %s\n", rt_last_error());
         return 1;
     }

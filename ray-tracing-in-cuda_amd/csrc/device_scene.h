@@ -54,6 +54,7 @@ struct RenderParams {
     DevCamera cam;
     float background[3];
     uint32_t flags;
+    float rr_p;              // Russian-roulette survival probability per bounce, 0 = off
     int32_t width, height, max_depth;
     // shard geometry (see rt_opts)
     int32_t tile_rows, tile_first, tile_stride, num_tiles, local_rows;

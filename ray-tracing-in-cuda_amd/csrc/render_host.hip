@@ -552,6 +552,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     }
     P.cam.lens_radius = cam.lens_radius;
     P.flags = s.flags;
+    P.rr_p = s.rr_p;
     P.width = s.width, P.height = s.height, P.max_depth = s.max_depth;
     P.tile_rows = sh.tile_rows, P.tile_first = sh.tile_first, P.tile_stride = sh.tile_stride;
     P.num_tiles = sh.num_tiles, P.local_rows = sh.local_rows;

@@ -329,6 +329,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 depth = P.max_depth;
                 active = true;
                 if (COUNT) c_samples++;
+                // Russian roulette before the first query (4_0_path_tracing.py:45-46): a sample that does
+                // not survive is black -- nothing to trace, nothing to add
+                // (a survivor's throughput is divided by p at once: include/rtmi.h, rt_scene_set_russian_roulette)
+                if (P.rr_p > 0.0f) {
+                    if (rng_next<COUNT>(rng) > P.rr_p) active = false;
+                    beta_r = beta_g = beta_b = 1.0f / P.rr_p;
+                }
             }
         }
         tick(0);
@@ -763,6 +770,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     rinv_a = 1.0f / ra;
                     depth--;
                     path_done = depth <= 0;  // main.cpp:42 / main.cu:69
+                    // Russian roulette before the next query: the path keeps what it has collected
+                    if (P.rr_p > 0.0f && !path_done) {
+                        if (rng_next<COUNT>(rng) > P.rr_p) path_done = true;
+                        beta_r = beta_r / P.rr_p, beta_g = beta_g / P.rr_p, beta_b = beta_b / P.rr_p;
+                    }
                 } else {
                     path_done = true;  // absorbed: main.cpp:32 / main.cu:55-58
                 }

@@ -273,6 +273,11 @@ int scene_from_json(const char *text, size_t len, Scene &s) {
         if (f->kind != JsonValue::Bool) r.fail("top level: \"defocus_blur\" must be a boolean");
         else if (!f->b) s.flags &= ~RT_FLAG_DEFOCUS_BLUR;
     }
+    if (root.find("russian_roulette")) {
+        const double p = r.num(root, "russian_roulette", "top level");
+        if (!(p >= 0.0 && p <= 1.0)) r.fail("top level: \"russian_roulette\" must be a probability in [0, 1]");
+        else s.rr_p = (float)p;
+    }
 
     // camera, parser.hpp:113-141
     const JsonValue *cam = root.find("camera");
@@ -453,6 +458,7 @@ std::string scene_to_json(const Scene &s) {
     o += "  \"height\": " + std::to_string(s.height) + ",\n";
     o += std::string("  \"sky_gradient\": ") + ((s.flags & RT_FLAG_SKY_GRADIENT) ? "true" : "false") + ",\n";
     o += std::string("  \"defocus_blur\": ") + ((s.flags & RT_FLAG_DEFOCUS_BLUR) ? "true" : "false") + ",\n";
+    if (s.rr_p > 0.0f) o += "  \"russian_roulette\": " + json_double((double)s.rr_p) + ",\n";
     o += "  \"camera\": {\"lookfrom\": ";
     put_vec3d(o, s.cam.lookfrom);
     o += ", \"lookat\": ";

@@ -35,6 +35,7 @@ struct Scene {
     int width = 400, height = 225, spp = 100, max_depth = 50;
     float background[3] = {0, 0, 0};
     uint32_t flags = 0;
+    float rr_p = 0.0f;  // Russian-roulette survival probability per bounce, 0 = off
     std::string output_file = "main.png";  // parser.hpp:566-567 default
     CameraParams cam;
     std::vector<rt_prim> prims;

@@ -36,7 +36,7 @@ class _RtoScene(C.Structure):
                 ("background", C.c_float * 3), ("cam", _RtoCamera),
                 ("prims", C.c_void_p), ("num_prims", C.c_int32),
                 ("mats", C.c_void_p), ("num_mats", C.c_int32),
-                ("texs", C.c_void_p), ("num_texs", C.c_int32)]
+                ("texs", C.c_void_p), ("num_texs", C.c_int32), ("rr_p", C.c_float)]
 
 
 class _RtoCounts(C.Structure):
@@ -133,6 +133,7 @@ class OracleScene:
         s.prims, s.num_prims = self.prims.ctypes.data, len(self.prims)
         s.mats, s.num_mats = self.mats.ctypes.data, len(self.mats)
         s.texs, s.num_texs = self.texs.ctypes.data, len(self.texs)
+        s.rr_p = info.russian_roulette
         self.c = s
         self.width, self.height, self.spp = info.width, info.height, info.samples_per_pixel
 
