@@ -31,7 +31,6 @@
 #endif
 
 // most short chunks at the end of a launch's work queue
-#define RT_MAX_TAIL 16
 
 namespace rtmi {
 
@@ -59,10 +58,10 @@ struct RenderParams {
     // shard geometry (see rt_opts)
     int32_t tile_rows, tile_first, tile_stride, num_tiles, local_rows;
     // samples
-    // samples [sample_first, +sample_count) are cut into n_big chunks of spp_chunk followed by chunks of
-    // shrinking tail chunks (the last work items of a launch are short, so its tail is short); num_chunks = total
-    int32_t sample_first, sample_count, spp_chunk, num_chunks, n_big;
-    int32_t tail_off[RT_MAX_TAIL + 1];  // sample offsets (from the end of the big chunks) of the tail chunks
+    // samples [sample_first, +sample_count) are cut into three runs of chunks, handed out in this order by the
+    // chunk-major queue: n_big chunks of spp_chunk, n_med chunks of q_med, then chunks of q_small to the end
+    // (guided self-scheduling: the later an item is handed out, the shorter it is); num_chunks = total
+    int32_t sample_first, sample_count, spp_chunk, num_chunks, n_big, n_med, q_med, q_small;
     uint32_t seed_lo, seed_hi;
     // scene image
     int32_t ns, nr, nc, nm;
@@ -95,6 +94,7 @@ struct DevCounters {
     unsigned long long groups_visited;           // culling: outer boxes that passed (per wave)
     unsigned long long lane_clusters, lane_groups;  // culling: boxes that passed, per lane
     unsigned long long t_start_min, t_start_max, t_end_min, t_end_max;  // s_memrealtime (100 MHz) of wave starts / exits
+    unsigned long long life_cycles, life_ticks;  // per-wave lifetime in shader cycles (s_memtime) and 100 MHz ticks, summed
     unsigned long long t_qe_min, t_qe_max;  // when a wave first found the queue empty
     unsigned int drain_hist[32];            // waves by time from queue-empty to exit, 50 us bins
     unsigned int qe_hist[1024];             // waves by time from their start to queue-empty, 64 us bins

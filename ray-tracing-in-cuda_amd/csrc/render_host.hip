@@ -430,39 +430,40 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         while (spp_chunk > 8 && tiles * ((sample_count + spp_chunk - 1) / spp_chunk) < want_items) spp_chunk /= 2;
     }
     if (spp_chunk > sample_count) spp_chunk = sample_count;
-    // The last big chunk (plus the remainder) is cut into quarter-size chunks: the queue hands them out
-    // last, so the tail of the launch (waves finishing their final item while the rest of the chip
-    // idles) is a quarter as long, while only one chunk's worth of samples pays the lower lane
-    // occupancy of short items.  Measured at 1080p: 128 spp 42.1 -> 37.0 ms, 1024 spp 263.9 -> 258.4 ms
-    // (a shrinking 1/4..1/16 plan, mode 2, measured the same).
-    int n_big = sample_count / spp_chunk;
-    int tail_samples = sample_count - n_big * spp_chunk;
-    const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob: 0 off, 1 quarters, 2 shrinking
-    const bool split_tail = n_big >= 2 && spp_chunk >= 32 && tail_mode > 0;
-    if (split_tail) {
-        n_big -= 1;
-        tail_samples += spp_chunk;
-    }
-    int tail_off[RT_MAX_TAIL + 1];
-    int n_small = 0;
-    tail_off[0] = 0;
+    // Guided self-scheduling of the chunk-major queue: big chunks first, then chunks a quarter as long, then
+    // a sixteenth.  A launch ends when the last wave finishes its last item, and an item over glass and
+    // dense spheres costs about three times the average one, so the run of medium items has to last as
+    // long as a heavy big item (and the run of small items as long as a heavy medium one) for the other
+    // waves to have something to do meanwhile.  What that takes depends on r = resident waves / tiles:
+    // a whole 1080p frame (r = 0.19) gives up one big chunk, a 1/8 row shard (r = 1.5) five, plus five
+    // medium chunks cut into 4-sample items.  Measured (RTIOW 1080p x 1024 spp, one of N shards on one
+    // GPU vs whole / N): see tools/gpu_scale.py and DESIGN.md.  Only the lower lane occupancy of short
+    // items is paid, and only by the last few percent of the samples.
+    const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob: 0 = off
+    int n_big = sample_count / spp_chunk, n_med = 0, q_med = spp_chunk, q_small = spp_chunk;
+    int num_chunks;
     {
-        const int q = spp_chunk / 4;
-        const int plan_geo[6] = {q, q, q, q / 2, q / 4, q / 4};
-        int left = tail_samples;
-        while (left > 0) {
-            int c = left;
-            if (split_tail) {
-                c = tail_mode == 2 && n_small < 6 ? plan_geo[n_small] : q;
-                if (c < 4) c = 4;
-                if (c > left || n_small == RT_MAX_TAIL - 1) c = left;
-            }
-            tail_off[n_small + 1] = tail_off[n_small] + c;
-            left -= c;
-            ++n_small;
+        const long long tiles = (long long)((s.width + 7) / 8) * ((sh.local_rows + 7) / 8);
+        const double r = 256.0 * 4 * RT_WAVES_PER_SIMD / (double)std::max(1LL, tiles);
+        const int rem = sample_count - n_big * spp_chunk;
+        int rest = rem;  // samples after the big chunks
+        if (tail_mode > 0 && spp_chunk >= 16 && n_big >= 1) {
+            const int n_split = std::min(n_big, std::max(1, (int)std::ceil(3.0 * r)));  // big chunks given up
+            n_big -= n_split;
+            rest += n_split * spp_chunk;
+            q_med = std::max(4, spp_chunk / 4);
+            q_small = std::max(4, q_med / 4);
+            int small_samples = 0;
+            if (r >= 0.5 && q_small < q_med)  // few tiles per wave: a run of small items as well
+                small_samples = std::min(rest - q_med, std::max(1, (int)std::ceil(3.0 * r)) * q_med);
+            if (small_samples < 0) small_samples = 0;
+            n_med = (rest - small_samples) / q_med;  // whole medium chunks; the small run takes what is left
+        } else {
+            q_med = q_small = spp_chunk;  // one run of equal chunks (the remainder is the last, shorter one)
         }
+        const int after_med = rest - n_med * q_med;
+        num_chunks = n_big + n_med + (after_med + q_small - 1) / q_small;
     }
-    int num_chunks = n_big + n_small;
     if (sample_first < 0) {
         set_error("sample_first must be >= 0");
         return RT_ERR_ARG;
@@ -558,8 +559,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     P.num_tiles = sh.num_tiles, P.local_rows = sh.local_rows;
     P.sample_first = sample_first, P.sample_count = sample_count;
     P.spp_chunk = spp_chunk, P.num_chunks = num_chunks;
-    P.n_big = n_big;
-    for (int i = 0; i <= RT_MAX_TAIL; ++i) P.tail_off[i] = i <= n_small ? tail_off[i] : tail_off[n_small];
+    P.n_big = n_big, P.n_med = n_med, P.q_med = q_med, P.q_small = q_small;
     uint64_t seed = o ? o->seed : 0;
     P.seed_lo = (uint32_t)seed, P.seed_hi = (uint32_t)(seed >> 32);
     P.tiles_x = (s.width + 7) / 8;
@@ -687,6 +687,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->wave_end_spread_us = (double)(h.t_end_max - h.t_end_min) * 0.01;
             stats->wave_span_us = (double)(h.t_end_max - h.t_start_min) * 0.01;
             if (getenv("RTMI_DEBUG_DRAIN")) {
+                fprintf(stderr, "shader clock over the waves' lifetimes: %.0f MHz\n", h.life_ticks ? 100.0 * (double)h.life_cycles / (double)h.life_ticks : 0.0);
                 fprintf(stderr, "queue-empty seen over %.1f us; first exit %.1f us after the first queue-empty; drain histogram (50 us bins):",
                         (double)(h.t_qe_max - h.t_qe_min) * 0.01, (double)(h.t_end_min - h.t_qe_min) * 0.01);
                 for (int i = 0; i < 32; ++i) fprintf(stderr, " %u", h.drain_hist[i]);

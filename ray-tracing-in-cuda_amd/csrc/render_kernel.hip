@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         }
     };
     if (COUNT) tmark = __builtin_amdgcn_s_memtime();
-    unsigned long long t_begin = 0;
-    if (COUNT) t_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_begin = 0, c_begin = 0;
+    if (COUNT) t_begin = __builtin_amdgcn_s_memrealtime(), c_begin = __builtin_amdgcn_s_memtime();
     if (COUNT && lane == 0) {
         const unsigned long long t = t_begin;
         atomicMin(&counters->t_start_min, t);
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     int c_hy = 0, c_hvalid = 0;  // this lane's home pixel in the current item (row, on-image)
     int mine = 0;                // !POOL: samples of the home pixel started so far (current item)
     bool in_old = false;         // this lane's live path belongs to the older item
+    int orphan = -1;             // >= 0: the path outlived its item; local pixel index for the global add
 
     // home pixel of this lane in the tile (x0, band): column, dense local row, image row, on-image
     auto home_pixel = [&](int x0, int band, int &hx, int &hlr, int &hy, int &hvalid) {
@@ -238,8 +239,20 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 if (POOL) exhausted = cursor >= c_pool;
                 else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine < c_nsamp) == 0ull;
             }
-            // then take the next one, unless the older item still occupies the second accumulator
-            if (exhausted && !queue_empty && !(c_valid && o_busy)) {
+            // then take the next one.  If the older item still occupies the second accumulator (a few
+            // stragglers on long paths), it is retired now: what it has collected is flushed, and its
+            // live lanes become orphans that add their sample straight to the global accumulators when
+            // they finish (integer sums: any split of an item's additions gives the same total).  So idle
+            // lanes never wait for stragglers, however short the items are.
+            if (exhausted && !queue_empty && c_valid && o_busy) {
+                flush_tile(o_acc, o_x0, o_band);
+                if (active && in_old) {
+                    orphan = (o_band * 8 + (cur_p >> 3)) * P.width + o_x0 + (cur_p & 7);  // dense local pixel index
+                    in_old = false;
+                }
+                o_busy = false;
+            }
+            if (exhausted && !queue_empty) {
                 unsigned int item = 0;
                 if (lane == 0) item = atomicAdd(queue, 1u);
                 item = __builtin_amdgcn_readfirstlane(item);
@@ -252,19 +265,22 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         unsigned long long *t = c_acc;
                         c_acc = o_acc, o_acc = t;
                         o_busy = true;
-                        in_old = active;
+                        in_old = active && orphan < 0;
                     }
                     c_x0 = (int)(item % (unsigned int)P.tiles_x) * 8;
                     c_band = (int)((item / (unsigned int)P.tiles_x) % (unsigned int)P.bands);
                     const int chunk = (int)(item / ((unsigned int)P.tiles_x * (unsigned int)P.bands));
-                    int s_stop;  // sample range: big chunks first, short ones at the end of the queue
+                    int s_stop;  // sample range: big chunks first, shorter and shorter ones towards the end of the queue
                     if (chunk < P.n_big) {
                         c_sbegin = P.sample_first + chunk * P.spp_chunk;
                         s_stop = c_sbegin + P.spp_chunk;
+                    } else if (chunk < P.n_big + P.n_med) {
+                        c_sbegin = P.sample_first + P.n_big * P.spp_chunk + (chunk - P.n_big) * P.q_med;
+                        s_stop = c_sbegin + P.q_med;
                     } else {
-                        const int base = P.sample_first + P.n_big * P.spp_chunk, k = chunk - P.n_big;
-                        c_sbegin = base + P.tail_off[k];
-                        s_stop = base + P.tail_off[k + 1];
+                        c_sbegin = P.sample_first + P.n_big * P.spp_chunk + P.n_med * P.q_med +
+                                   (chunk - P.n_big - P.n_med) * P.q_small;
+                        s_stop = c_sbegin + P.q_small;
                     }
                     if (s_stop > P.sample_first + P.sample_count) s_stop = P.sample_first + P.sample_count;
                     c_nsamp = s_stop - c_sbegin;
@@ -794,10 +810,18 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             }
             tick(3);
             if (path_done) {  // res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
-                unsigned long long *a = (in_old ? o_acc : c_acc) + cur_p * 3;
-                atomicAdd(a + 0, radiance_to_fixed(L_r));
-                atomicAdd(a + 1, radiance_to_fixed(L_g));
-                atomicAdd(a + 2, radiance_to_fixed(L_b));
+                if (orphan >= 0) {
+                    unsigned long long *g = acc + (size_t)orphan * 3;
+                    atomicAdd(g + 0, radiance_to_fixed(L_r));
+                    atomicAdd(g + 1, radiance_to_fixed(L_g));
+                    atomicAdd(g + 2, radiance_to_fixed(L_b));
+                    orphan = -1;
+                } else {
+                    unsigned long long *a = (in_old ? o_acc : c_acc) + cur_p * 3;
+                    atomicAdd(a + 0, radiance_to_fixed(L_r));
+                    atomicAdd(a + 1, radiance_to_fixed(L_g));
+                    atomicAdd(a + 2, radiance_to_fixed(L_b));
+                }
                 active = false;
             }
             tick(4);
@@ -833,6 +857,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
             atomicMin(&counters->t_end_min, t);
             atomicMax(&counters->t_end_max, t);
+            atomicAdd(&counters->life_cycles, __builtin_amdgcn_s_memtime() - c_begin);
+            atomicAdd(&counters->life_ticks, t - t_begin);
             atomicMin(&counters->t_qe_min, t_qe);
             atomicMax(&counters->t_qe_max, t_qe);
             const unsigned long long bin = (t - t_qe) / 5000ull;  // 100 MHz ticks -> 50 us bins

@@ -1,11 +1,20 @@
+"""What one rank of an N-GPU strong-scaled run executes, timed on one GPU: the row-tile shard r = 0 of N
+(interleaved 8-row tiles) of the bench frame, for N = 1, 2, 4, 8, against the whole frame / N."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 rtmi = load_package()
-for (w, h, spp) in [(1920, 1080, 256), (960, 540, 1024), (1920, 1080, 128), (1920, 135, 1024), (3840, 2160, 64), (1920, 1080, 1024), (1920, 1080, 2048)]:
-    sc = rtmi.Scene.rtiow(7, w, h, spp, 50)
-    best = 1e9
-    for rep in range(3):
-        st = rtmi.Stats(); sc.render(rtmi.Opts(seed=2023), st); best = min(best, st.kernel_ms)
-    print(f"{w}x{h}x{spp}: {best:.2f} ms  {w*h*spp/best/1e3:.0f} Msamples/s  ({w*h*spp/1e6:.0f} Msamples)", flush=True)
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+sc = rtmi.Scene.rtiow(7, 1920, 1080, spp, 50)
+whole = None
+for n in (1, 2, 4, 8):
+    ts = []
+    for r in sorted({0, n - 1}):
+        best = 1e9
+        for rep in range(3):
+            st = rtmi.Stats(); sc.render(rtmi.Opts(seed=2023, tile_first=r, tile_stride=n), st); best = min(best, st.kernel_ms)
+        ts.append(best)
+    t = max(ts)
+    if n == 1: whole = t
+    print(f"N={n}: slowest of ranks 0 and {n-1}: {t:.2f} ms; whole/N = {whole/n:.2f} ms; predicted efficiency {whole/n/t*100:.1f} %", flush=True)
