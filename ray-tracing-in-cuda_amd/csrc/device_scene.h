@@ -43,14 +43,9 @@ enum MatKind : int32_t {
     MK_LIGHT_CHECKER = 5     // c0 = even, c1 = odd
 };
 
-struct DevCamera {
-    float origin[3], lower_left[3], horizontal[3], vertical[3], u[3], v[3];
-    float lens_radius;
-};
-
 // kernel parameter block (passed by value: lands in SGPRs / the kernarg segment)
 struct RenderParams {
-    DevCamera cam;
+    int32_t off_cam;         // 6 records of the hot table: {origin, lens_radius}, lower_left, horizontal, vertical, u, v
     float background[3];
     uint32_t flags;
     float rr_p;              // Russian-roulette survival probability per bounce, 0 = off

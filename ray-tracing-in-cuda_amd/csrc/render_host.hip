@@ -163,6 +163,8 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     off += 4 * L.nc;
     L.off_cbox = off;
     off += 2 * L.nc;
+    L.off_cam = off;  // camera::camera's derived vectors (camera.h:9-31): read once per new sample
+    off += 6;
     L.hot_vec4 = off;
     L.off_sph_cold = off;
     off += ns_slots;
@@ -176,6 +178,16 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     float *I = c.image.data();
     auto rec4 = [&](int idx) { return I + (size_t)idx * 4; };
 
+    {
+        rt_camera cam;
+        derive_camera(s, &cam);
+        const float *src[6] = {cam.origin, cam.lower_left, cam.horizontal, cam.vertical, cam.u, cam.v};
+        for (int k = 0; k < 6; ++k) {
+            float *h = rec4(L.off_cam + k);
+            h[0] = src[k][0], h[1] = src[k][1], h[2] = src[k][2];
+        }
+        rec4(L.off_cam)[3] = cam.lens_radius;
+    }
     for (int k = 0; k < ns_slots + 4; ++k) {
         float *h = rec4(k);
         const int pi = k < ns_slots ? slots[k] : -1;
@@ -540,18 +552,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
 
     // ---- kernel parameters
     RenderParams P = cache.layout;
-    rt_camera cam;
-    derive_camera(s, &cam);
-    for (int i = 0; i < 3; ++i) {
-        P.cam.origin[i] = cam.origin[i];
-        P.cam.lower_left[i] = cam.lower_left[i];
-        P.cam.horizontal[i] = cam.horizontal[i];
-        P.cam.vertical[i] = cam.vertical[i];
-        P.cam.u[i] = cam.u[i];
-        P.cam.v[i] = cam.v[i];
-        P.background[i] = s.background[i];
-    }
-    P.cam.lens_radius = cam.lens_radius;
+    for (int i = 0; i < 3; ++i) P.background[i] = s.background[i];
     P.flags = s.flags;
     P.rr_p = s.rr_p;
     P.width = s.width, P.height = s.height, P.max_depth = s.max_depth;
@@ -585,6 +586,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     if (lds_bytes > 64 * 1024 && set_max_dynamic_lds(lds_bytes)) {
         set_error("cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
         return RT_ERR_HIP;
+    }
+    if (s.width > 65536 || P.bands > 32767) {  // the kernel packs (tile x0, band) of a wave's older item into one register
+        set_error("frame of %d x %d rows per shard exceeds the tile index range (65536 columns, 262136 rows)", s.width,
+                  sh.local_rows);
+        return RT_ERR_LIMIT;
     }
     const size_t plane = (size_t)sh.local_rows * s.width * 3;
     const unsigned long long items64 = (unsigned long long)P.tiles_x * P.bands * num_chunks;

@@ -184,13 +184,14 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     // of the workgroup never synchronise again.
     unsigned long long *c_acc = my_acc;        // accumulator of the current item (wave-uniform pointers)
     unsigned long long *o_acc = my_acc + 192;  //                 of the older item
-    int c_x0 = 0, c_band = 0, c_sbegin = 0, c_nsamp = 0, c_pool = 0, cursor = 0;
-    int o_x0 = 0, o_band = 0;
+    int c_x0 = 0, c_band = 0, c_sbegin = 0, c_pool = 0, cursor = 0;  // c_pool = 64 x samples of the item
+    int o_tile = 0;  // older item: x0 | band << 16
     bool c_valid = false, o_busy = false, queue_empty = false;
     int c_hy = 0, c_hvalid = 0;  // this lane's home pixel in the current item (row, on-image)
     int mine = 0;                // !POOL: samples of the home pixel started so far (current item)
-    bool in_old = false;         // this lane's live path belongs to the older item
-    int orphan = -1;             // >= 0: the path outlived its item; local pixel index for the global add
+    // where this lane's live path adds its sample: -2 the current item's accumulator, -1 the older item's,
+    // >= 0 the path outlived its item (an orphan): local pixel index for a direct global add
+    int slot = -2;
 
     // home pixel of this lane in the tile (x0, band): column, dense local row, image row, on-image
     auto home_pixel = [&](int x0, int band, int &hx, int &hlr, int &hy, int &hvalid) {
@@ -232,27 +233,38 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         // (render()'s sample loop, main.cu:95-101; camera::get_ray camera.h:32-39)
         const bool need = !active;
         const unsigned long long idle = __ballot(need);
-        if (idle) {  // wave-uniform
-            // is the current item handed out completely?
-            bool exhausted = !c_valid;
-            if (c_valid) {
-                if (POOL) exhausted = cursor >= c_pool;
-                else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine < c_nsamp) == 0ull;
-            }
-            // then take the next one.  If the older item still occupies the second accumulator (a few
-            // stragglers on long paths), it is retired now: what it has collected is flushed, and its
-            // live lanes become orphans that add their sample straight to the global accumulators when
-            // they finish (integer sums: any split of an item's additions gives the same total).  So idle
-            // lanes never wait for stragglers, however short the items are.
-            if (exhausted && !queue_empty && c_valid && o_busy) {
+        // is the current item handed out completely?
+        bool exhausted = !c_valid;
+        if (c_valid) {
+            if (POOL) exhausted = cursor >= c_pool;
+            else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
+        }
+        // The older item leaves its accumulator (the one flush site of the loop) when its last path has
+        // ended -- or when idle lanes need the slot for the next item while a few stragglers are still on
+        // long paths: what it has collected is flushed now, and those lanes become orphans that add their
+        // sample straight to the global accumulators when they finish (integer sums: any split of an
+        // item's additions gives the same total).  So idle lanes never wait for stragglers, however short
+        // the items are.
+        if (o_busy) {
+            const bool live_old = active && slot == -1;
+            const bool none_left = __builtin_amdgcn_ballot_w64(live_old) == 0ull;
+#ifdef RT_NO_ORPHANS
+            if (none_left) {
+#else
+            if (none_left || (idle != 0ull && exhausted && !queue_empty)) {
+#endif
+                const int o_x0 = o_tile & 0xffff, o_band = o_tile >> 16;
+                if (live_old) slot = (o_band * 8 + (cur_p >> 3)) * P.width + o_x0 + (cur_p & 7);  // dense local pixel index
                 flush_tile(o_acc, o_x0, o_band);
-                if (active && in_old) {
-                    orphan = (o_band * 8 + (cur_p >> 3)) * P.width + o_x0 + (cur_p & 7);  // dense local pixel index
-                    in_old = false;
-                }
                 o_busy = false;
             }
+        }
+        if (idle) {  // wave-uniform
+#ifdef RT_NO_ORPHANS
+            if (exhausted && !queue_empty && !(c_valid && o_busy)) {
+#else
             if (exhausted && !queue_empty) {
+#endif
                 unsigned int item = 0;
                 if (lane == 0) item = atomicAdd(queue, 1u);
                 item = __builtin_amdgcn_readfirstlane(item);
@@ -261,11 +273,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     if (COUNT) t_qe = __builtin_amdgcn_s_memrealtime();
                 } else {
                     if (c_valid) {  // the current item becomes the older one; every live path is its
-                        o_x0 = c_x0, o_band = c_band;
+                        o_tile = c_x0 | (c_band << 16);
                         unsigned long long *t = c_acc;
                         c_acc = o_acc, o_acc = t;
                         o_busy = true;
-                        in_old = active && orphan < 0;
+                        if (active && slot == -2) slot = -1;
                     }
                     c_x0 = (int)(item % (unsigned int)P.tiles_x) * 8;
                     c_band = (int)((item / (unsigned int)P.tiles_x) % (unsigned int)P.bands);
@@ -283,8 +295,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         s_stop = c_sbegin + P.q_small;
                     }
                     if (s_stop > P.sample_first + P.sample_count) s_stop = P.sample_first + P.sample_count;
-                    c_nsamp = s_stop - c_sbegin;
-                    c_pool = c_nsamp * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
+                    c_pool = (s_stop - c_sbegin) * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
                     cursor = 0;
                     mine = 0;
                     c_valid = true;
@@ -307,37 +318,43 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 ss = c_sbegin + (k >> 6);
                 start = need && c_valid && k < c_pool && pv != 0;
             } else {
-                start = need && c_valid && mine < c_nsamp && c_hvalid != 0;
+                start = need && c_valid && mine * 64 < c_pool && c_hvalid != 0;
                 sp = lane, spx = c_x0 + (lane & 7), spy = c_hy, ss = c_sbegin + mine;
                 if (start) mine++;
             }
             if (start) {
                 cur_p = sp;
-                in_old = false;
+                slot = -2;
                 rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss, k0, k1);
                 float u = ((float)spx + rng_next<COUNT>(rng)) / wm1;
                 float v = ((float)spy + rng_next<COUNT>(rng)) / hm1;
                 float offx = 0.0f, offy = 0.0f, offz = 0.0f;
+                // the camera's derived vectors come from the hot table (wave-uniform reads, used here only),
+                // not from kernel arguments that would sit in SGPRs for the whole launch
+                const float4 *cv = hot + P.off_cam;
+                const float4 c_org = cv[0];  // origin, lens_radius
                 if (P.flags & RT_FLAG_DEFOCUS_BLUR) {
                     float px, py;
                     do {  // random_in_unit_disk, vec3.h:157-165
                         px = rng_pm1<COUNT>(rng);
                         py = rng_pm1<COUNT>(rng);
                     } while (fmaf(px, px, py * py) >= 1.0f);
-                    float rdx = P.cam.lens_radius * px, rdy = P.cam.lens_radius * py;
-                    offx = fmaf(P.cam.u[0], rdx, P.cam.v[0] * rdy);
-                    offy = fmaf(P.cam.u[1], rdx, P.cam.v[1] * rdy);
-                    offz = fmaf(P.cam.u[2], rdx, P.cam.v[2] * rdy);
+                    const float4 c_u = cv[4], c_v = cv[5];
+                    float rdx = c_org.w * px, rdy = c_org.w * py;
+                    offx = fmaf(c_u.x, rdx, c_v.x * rdy);
+                    offy = fmaf(c_u.y, rdx, c_v.y * rdy);
+                    offz = fmaf(c_u.z, rdx, c_v.z * rdy);
                 }
-                dx = fmaf(v, P.cam.vertical[0], fmaf(u, P.cam.horizontal[0], P.cam.lower_left[0]));
-                dy = fmaf(v, P.cam.vertical[1], fmaf(u, P.cam.horizontal[1], P.cam.lower_left[1]));
-                dz = fmaf(v, P.cam.vertical[2], fmaf(u, P.cam.horizontal[2], P.cam.lower_left[2]));
-                dx = (dx - P.cam.origin[0]) - offx;
-                dy = (dy - P.cam.origin[1]) - offy;
-                dz = (dz - P.cam.origin[2]) - offz;
-                ox = P.cam.origin[0] + offx;
-                oy = P.cam.origin[1] + offy;
-                oz = P.cam.origin[2] + offz;
+                const float4 c_ll = cv[1], c_hor = cv[2], c_ver = cv[3];
+                dx = fmaf(v, c_ver.x, fmaf(u, c_hor.x, c_ll.x));
+                dy = fmaf(v, c_ver.y, fmaf(u, c_hor.y, c_ll.y));
+                dz = fmaf(v, c_ver.z, fmaf(u, c_hor.z, c_ll.z));
+                dx = (dx - c_org.x) - offx;
+                dy = (dy - c_org.y) - offy;
+                dz = (dz - c_org.z) - offz;
+                ox = c_org.x + offx;
+                oy = c_org.y + offy;
+                oz = c_org.z + offz;
                 ra = dot3(dx, dy, dz, dx, dy, dz);
                 rinv_a = 1.0f / ra;
                 beta_r = beta_g = beta_b = 1.0f;
@@ -355,11 +372,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             }
         }
         tick(0);
-        // the older item retires when its last path has ended
-        if (o_busy && __builtin_amdgcn_ballot_w64(active && in_old) == 0ull) {
-            flush_tile(o_acc, o_x0, o_band);
-            o_busy = false;
-        }
         if (!__any(active)) {
             // nothing in flight (so the older item is already flushed).  Out of work when the queue is
             // dry and the current item is handed out; otherwise loop: the refill above makes progress
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             bool exhausted = !c_valid;
             if (c_valid) {
                 if (POOL) exhausted = cursor >= c_pool;
-                else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine < c_nsamp) == 0ull;
+                else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
             }
             if (queue_empty && exhausted) {
                 if (c_valid) flush_tile(c_acc, c_x0, c_band);
@@ -810,14 +822,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             }
             tick(3);
             if (path_done) {  // res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
-                if (orphan >= 0) {
-                    unsigned long long *g = acc + (size_t)orphan * 3;
+                if (slot >= 0) {
+                    unsigned long long *g = acc + (size_t)slot * 3;
                     atomicAdd(g + 0, radiance_to_fixed(L_r));
                     atomicAdd(g + 1, radiance_to_fixed(L_g));
                     atomicAdd(g + 2, radiance_to_fixed(L_b));
-                    orphan = -1;
                 } else {
-                    unsigned long long *a = (in_old ? o_acc : c_acc) + cur_p * 3;
+                    unsigned long long *a = (slot == -1 ? o_acc : c_acc) + cur_p * 3;
                     atomicAdd(a + 0, radiance_to_fixed(L_r));
                     atomicAdd(a + 1, radiance_to_fixed(L_g));
                     atomicAdd(a + 2, radiance_to_fixed(L_b));
