@@ -26,6 +26,7 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
                    DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant);
 int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes);
 void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream);
+void launch_item_params(unsigned int *queue, const ItemParams &ip, hipStream_t stream);
 int set_max_dynamic_lds(size_t bytes);
 bool variant_exists(unsigned variant);
 
@@ -630,7 +631,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         // accumulators + the work-queue counter behind them, cleared together.  They belong to this
         // (scene, device): concurrent renders of ONE scene object on one device must share a stream
         // (different scene objects, or clones, are independent)
-        const size_t need = plane * sizeof(unsigned long long) + 64;
+        const size_t need = plane * sizeof(unsigned long long) + 256;  // + queue counter and ItemParams
         if (ent->acc_bytes < need) {
             if (ent->d_acc) HIP_TRY(hipFree(ent->d_acc));
             ent->d_acc = nullptr;
@@ -642,6 +643,15 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         // progressive rendering: continue from the caller's exact sums
         if (h_acc) HIP_TRY(hipMemcpyAsync(ent->d_acc, h_acc, plane * sizeof(long long), hipMemcpyHostToDevice, stream));
         unsigned int *d_queue = reinterpret_cast<unsigned int *>(ent->d_acc + plane);
+        {  // what a wave reads when it fetches or flushes an item (kept out of the kernel's SGPRs)
+            ItemParams ip;
+            ip.tiles_x = P.tiles_x, ip.bands = P.bands, ip.num_items = P.num_items;
+            ip.sample_first = P.sample_first, ip.sample_count = P.sample_count, ip.spp_chunk = P.spp_chunk;
+            ip.n_big = P.n_big, ip.n_med = P.n_med, ip.q_med = P.q_med, ip.q_small = P.q_small;
+            ip.tile_rows = P.tile_rows, ip.tile_first = P.tile_first, ip.tile_stride = P.tile_stride;
+            ip.local_rows = P.local_rows;
+            launch_item_params(d_queue, ip, stream);
+        }
         // nothing worth culling (no sphere clusters, a handful of cylinders): the plain scan is the
         // same result without the per-query box set-up
         unsigned launch_variant = variant;

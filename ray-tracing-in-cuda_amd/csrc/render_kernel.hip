@@ -194,12 +194,17 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     int slot = -2;
 
     // home pixel of this lane in the tile (x0, band): column, dense local row, image row, on-image
+    // item-level launch values, read where they are needed (device_scene.h, ItemParams)
+    auto ipar = [&](int k) {
+        return __builtin_amdgcn_readfirstlane(reinterpret_cast<const volatile int *>(queue)[RT_ITEM_PARAMS_AT + k]);
+    };
     auto home_pixel = [&](int x0, int band, int &hx, int &hlr, int &hy, int &hvalid) {
+        const int tile_rows = ipar(IP_TILE_ROWS), tile_first = ipar(IP_TILE_FIRST), tile_stride = ipar(IP_TILE_STRIDE);
         hx = x0 + (lane & 7);
         hlr = band * 8 + (lane >> 3);
-        const int htl = hlr / P.tile_rows;
-        hy = (P.tile_first + htl * P.tile_stride) * P.tile_rows + (hlr - htl * P.tile_rows);
-        hvalid = (hx < P.width && hlr < P.local_rows && hy < P.height) ? 1 : 0;
+        const int htl = hlr / tile_rows;
+        hy = (tile_first + htl * tile_stride) * tile_rows + (hlr - htl * tile_rows);
+        hvalid = (hx < P.width && hlr < ipar(IP_LOCAL_ROWS) && hy < P.height) ? 1 : 0;
     };
     // tile accumulator -> global accumulators (image[y*W + x] += res, main.cu:104; one 64-bit atomic per
     // channel: other sample chunks of the same pixels are other work items), then clear it for reuse
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 unsigned int item = 0;
                 if (lane == 0) item = atomicAdd(queue, 1u);
                 item = __builtin_amdgcn_readfirstlane(item);
-                if (item >= (unsigned int)P.num_items) {
+                if (item >= (unsigned int)ipar(IP_NUM_ITEMS)) {
                     queue_empty = true;  // the counter only grows: every wave gets here
                     if (COUNT) t_qe = __builtin_amdgcn_s_memrealtime();
                 } else {
@@ -279,22 +284,26 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         o_busy = true;
                         if (active && slot == -2) slot = -1;
                     }
-                    c_x0 = (int)(item % (unsigned int)P.tiles_x) * 8;
-                    c_band = (int)((item / (unsigned int)P.tiles_x) % (unsigned int)P.bands);
-                    const int chunk = (int)(item / ((unsigned int)P.tiles_x * (unsigned int)P.bands));
+                    const unsigned int tiles_x = (unsigned int)ipar(IP_TILES_X), bands = (unsigned int)ipar(IP_BANDS);
+                    const int sample_first = ipar(IP_SAMPLE_FIRST), spp_chunk = ipar(IP_SPP_CHUNK);
+                    const int n_big = ipar(IP_N_BIG), n_med = ipar(IP_N_MED), q_med = ipar(IP_Q_MED);
+                    c_x0 = (int)(item % tiles_x) * 8;
+                    c_band = (int)((item / tiles_x) % bands);
+                    const int chunk = (int)(item / (tiles_x * bands));
                     int s_stop;  // sample range: big chunks first, shorter and shorter ones towards the end of the queue
-                    if (chunk < P.n_big) {
-                        c_sbegin = P.sample_first + chunk * P.spp_chunk;
-                        s_stop = c_sbegin + P.spp_chunk;
-                    } else if (chunk < P.n_big + P.n_med) {
-                        c_sbegin = P.sample_first + P.n_big * P.spp_chunk + (chunk - P.n_big) * P.q_med;
-                        s_stop = c_sbegin + P.q_med;
+                    if (chunk < n_big) {
+                        c_sbegin = sample_first + chunk * spp_chunk;
+                        s_stop = c_sbegin + spp_chunk;
+                    } else if (chunk < n_big + n_med) {
+                        c_sbegin = sample_first + n_big * spp_chunk + (chunk - n_big) * q_med;
+                        s_stop = c_sbegin + q_med;
                     } else {
-                        c_sbegin = P.sample_first + P.n_big * P.spp_chunk + P.n_med * P.q_med +
-                                   (chunk - P.n_big - P.n_med) * P.q_small;
-                        s_stop = c_sbegin + P.q_small;
+                        const int q_small = ipar(IP_Q_SMALL);
+                        c_sbegin = sample_first + n_big * spp_chunk + n_med * q_med + (chunk - n_big - n_med) * q_small;
+                        s_stop = c_sbegin + q_small;
                     }
-                    if (s_stop > P.sample_first + P.sample_count) s_stop = P.sample_first + P.sample_count;
+                    const int s_end = sample_first + ipar(IP_SAMPLE_COUNT);
+                    if (s_stop > s_end) s_stop = s_end;
                     c_pool = (s_stop - c_sbegin) * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
                     cursor = 0;
                     mine = 0;
@@ -952,6 +961,17 @@ bool variant_exists(unsigned variant) {
     RT_VARIANT_TABLE(RT_HAS)
 #undef RT_HAS
     return false;
+}
+
+__global__ void item_params_kernel(unsigned int *queue, ItemParams ip) {
+    int *dst = reinterpret_cast<int *>(queue) + RT_ITEM_PARAMS_AT;
+    const int v[IP_COUNT] = {ip.tiles_x, ip.bands, ip.num_items, ip.sample_first, ip.sample_count, ip.spp_chunk, ip.n_big,
+                             ip.n_med, ip.q_med, ip.q_small, ip.tile_rows, ip.tile_first, ip.tile_stride, ip.local_rows};
+    for (int k = 0; k < IP_COUNT; ++k) dst[k] = v[k];
+}
+
+void launch_item_params(unsigned int *queue, const ItemParams &ip, hipStream_t stream) {
+    hipLaunchKernelGGL(item_params_kernel, dim3(1), dim3(1), 0, stream, queue, ip);
 }
 
 void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream) {
