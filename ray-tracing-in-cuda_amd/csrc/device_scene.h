@@ -44,15 +44,13 @@ enum MatKind : int32_t {
 };
 
 // Per-launch values the kernel needs only when a wave fetches or flushes a work item.  They live in global
-// memory behind the queue counter (queue[RT_ITEM_PARAMS_AT + k], written by a one-thread kernel before the
-// render launch) and are read there, instead of occupying 14 SGPRs for the whole launch.
+// memory behind the queue counter (16 ints at queue[RT_ITEM_PARAMS_AT], written by a one-thread kernel before the
+// render launch; layout in item_params_kernel) and are read there, instead of occupying 14 SGPRs for the whole launch.
 #define RT_ITEM_PARAMS_AT 16
 struct ItemParams {
     int32_t tiles_x, bands, num_items, sample_first, sample_count, spp_chunk, n_big, n_med, q_med, q_small;
     int32_t tile_rows, tile_first, tile_stride, local_rows;
 };
-enum { IP_TILES_X, IP_BANDS, IP_NUM_ITEMS, IP_SAMPLE_FIRST, IP_SAMPLE_COUNT, IP_SPP_CHUNK, IP_N_BIG, IP_N_MED, IP_Q_MED,
-       IP_Q_SMALL, IP_TILE_ROWS, IP_TILE_FIRST, IP_TILE_STRIDE, IP_LOCAL_ROWS, IP_COUNT };
 
 // kernel parameter block (passed by value: lands in SGPRs / the kernarg segment)
 struct RenderParams {

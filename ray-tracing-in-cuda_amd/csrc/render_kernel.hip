@@ -194,17 +194,21 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     int slot = -2;
 
     // home pixel of this lane in the tile (x0, band): column, dense local row, image row, on-image
-    // item-level launch values, read where they are needed (device_scene.h, ItemParams)
-    auto ipar = [&](int k) {
-        return __builtin_amdgcn_readfirstlane(reinterpret_cast<const volatile int *>(queue)[RT_ITEM_PARAMS_AT + k]);
+    // item-level launch values, read where they are needed (device_scene.h, ItemParams): wave-uniform
+    // 16-byte loads behind a compiler barrier, so that they are neither hoisted out of the main loop (and
+    // then spilled) nor kept in registers between items
+    auto ipar4 = [&](int quad) {
+        asm volatile("" ::: "memory");
+        return reinterpret_cast<const int4 *>(queue + RT_ITEM_PARAMS_AT)[quad];
     };
     auto home_pixel = [&](int x0, int band, int &hx, int &hlr, int &hy, int &hvalid) {
-        const int tile_rows = ipar(IP_TILE_ROWS), tile_first = ipar(IP_TILE_FIRST), tile_stride = ipar(IP_TILE_STRIDE);
+        const int4 g = ipar4(3);  // q_small (unused here) is not in this quad: {tile_rows, tile_first, tile_stride, local_rows}
+        const int tile_rows = g.x, tile_first = g.y, tile_stride = g.z, local_rows = g.w;
         hx = x0 + (lane & 7);
         hlr = band * 8 + (lane >> 3);
         const int htl = hlr / tile_rows;
         hy = (tile_first + htl * tile_stride) * tile_rows + (hlr - htl * tile_rows);
-        hvalid = (hx < P.width && hlr < ipar(IP_LOCAL_ROWS) && hy < P.height) ? 1 : 0;
+        hvalid = (hx < P.width && hlr < local_rows && hy < P.height) ? 1 : 0;
     };
     // tile accumulator -> global accumulators (image[y*W + x] += res, main.cu:104; one 64-bit atomic per
     // channel: other sample chunks of the same pixels are other work items), then clear it for reuse
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 unsigned int item = 0;
                 if (lane == 0) item = atomicAdd(queue, 1u);
                 item = __builtin_amdgcn_readfirstlane(item);
-                if (item >= (unsigned int)ipar(IP_NUM_ITEMS)) {
+                const int4 ia = ipar4(0), ib = ipar4(1), ic = ipar4(2);
+                if (item >= (unsigned int)ia.z) {
                     queue_empty = true;  // the counter only grows: every wave gets here
                     if (COUNT) t_qe = __builtin_amdgcn_s_memrealtime();
                 } else {
@@ -284,9 +289,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         o_busy = true;
                         if (active && slot == -2) slot = -1;
                     }
-                    const unsigned int tiles_x = (unsigned int)ipar(IP_TILES_X), bands = (unsigned int)ipar(IP_BANDS);
-                    const int sample_first = ipar(IP_SAMPLE_FIRST), spp_chunk = ipar(IP_SPP_CHUNK);
-                    const int n_big = ipar(IP_N_BIG), n_med = ipar(IP_N_MED), q_med = ipar(IP_Q_MED);
+                    const unsigned int tiles_x = (unsigned int)ia.x, bands = (unsigned int)ia.y;
+                    const int sample_first = ia.w, sample_count = ib.x, spp_chunk = ib.y;
+                    const int n_big = ib.z, n_med = ib.w, q_med = ic.x, q_small = ic.y;
                     c_x0 = (int)(item % tiles_x) * 8;
                     c_band = (int)((item / tiles_x) % bands);
                     const int chunk = (int)(item / (tiles_x * bands));
@@ -298,11 +303,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         c_sbegin = sample_first + n_big * spp_chunk + (chunk - n_big) * q_med;
                         s_stop = c_sbegin + q_med;
                     } else {
-                        const int q_small = ipar(IP_Q_SMALL);
                         c_sbegin = sample_first + n_big * spp_chunk + n_med * q_med + (chunk - n_big - n_med) * q_small;
                         s_stop = c_sbegin + q_small;
                     }
-                    const int s_end = sample_first + ipar(IP_SAMPLE_COUNT);
+                    const int s_end = sample_first + sample_count;
                     if (s_stop > s_end) s_stop = s_end;
                     c_pool = (s_stop - c_sbegin) * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
                     cursor = 0;
@@ -965,9 +969,11 @@ bool variant_exists(unsigned variant) {
 
 __global__ void item_params_kernel(unsigned int *queue, ItemParams ip) {
     int *dst = reinterpret_cast<int *>(queue) + RT_ITEM_PARAMS_AT;
-    const int v[IP_COUNT] = {ip.tiles_x, ip.bands, ip.num_items, ip.sample_first, ip.sample_count, ip.spp_chunk, ip.n_big,
-                             ip.n_med, ip.q_med, ip.q_small, ip.tile_rows, ip.tile_first, ip.tile_stride, ip.local_rows};
-    for (int k = 0; k < IP_COUNT; ++k) dst[k] = v[k];
+    // quad 0: tiles_x, bands, num_items, sample_first; quad 1: sample_count, spp_chunk, n_big, n_med;
+    // quad 2: q_med, q_small, -, -; quad 3: tile_rows, tile_first, tile_stride, local_rows
+    const int v[16] = {ip.tiles_x, ip.bands, ip.num_items, ip.sample_first, ip.sample_count, ip.spp_chunk, ip.n_big,
+                       ip.n_med, ip.q_med, ip.q_small, 0, 0, ip.tile_rows, ip.tile_first, ip.tile_stride, ip.local_rows};
+    for (int k = 0; k < 16; ++k) dst[k] = v[k];
 }
 
 void launch_item_params(unsigned int *queue, const ItemParams &ip, hipStream_t stream) {
