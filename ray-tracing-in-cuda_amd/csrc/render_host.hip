@@ -631,7 +631,10 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         // accumulators + the work-queue counter behind them, cleared together.  They belong to this
         // (scene, device): concurrent renders of ONE scene object on one device must share a stream
         // (different scene objects, or clones, are independent)
-        const size_t need = plane * sizeof(unsigned long long) + 256;  // + queue counter and ItemParams
+        // accumulators, then (256-byte aligned: the kernel reads the ItemParams with 16-byte loads) the queue
+        // counter and the ItemParams
+        const size_t queue_off = (plane * sizeof(unsigned long long) + 255) & ~(size_t)255;
+        const size_t need = queue_off + 256;
         if (ent->acc_bytes < need) {
             if (ent->d_acc) HIP_TRY(hipFree(ent->d_acc));
             ent->d_acc = nullptr;
@@ -642,7 +645,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         HIP_TRY(hipMemsetAsync(ent->d_acc, 0, need, stream));
         // progressive rendering: continue from the caller's exact sums
         if (h_acc) HIP_TRY(hipMemcpyAsync(ent->d_acc, h_acc, plane * sizeof(long long), hipMemcpyHostToDevice, stream));
-        unsigned int *d_queue = reinterpret_cast<unsigned int *>(ent->d_acc + plane);
+        unsigned int *d_queue = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(ent->d_acc) + queue_off);
         {  // what a wave reads when it fetches or flushes an item (kept out of the kernel's SGPRs)
             ItemParams ip;
             ip.tiles_x = P.tiles_x, ip.bands = P.bands, ip.num_items = P.num_items;
