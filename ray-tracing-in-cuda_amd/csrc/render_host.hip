@@ -438,7 +438,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     int spp_chunk = (o && o->spp_chunk > 0) ? o->spp_chunk : 0;
     if (spp_chunk == 0) {
         const long long tiles = (long long)((s.width + 7) / 8) * ((sh.local_rows + 7) / 8);
-        const long long want_items = 4LL * 256 * 6 * 4;  // 4 items per resident wave
+        const long long want_items = 4LL * 256 * RT_WAVES_PER_SIMD * 4;  // 4 items per resident wave
         spp_chunk = 64;
         while (spp_chunk > 8 && tiles * ((sample_count + spp_chunk - 1) / spp_chunk) < want_items) spp_chunk /= 2;
     }
