@@ -551,14 +551,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                             const int base = P.np + RT_CLUSTER * (g0 * RT_GROUP + q);
                             const float4 *cs = sph + base;
                             // four records at a time: eight in flight cost 20 spilled VGPRs at 6 waves/SIMD
-#ifdef RT_BATCH2
-#pragma unroll
-                            for (int h = 0; h < RT_CLUSTER; h += 2) {
-                                const float4 r0 = cs[h], r1 = cs[h + 1];
-                                RT_SPHERE_TEST(r0, base + h)
-                                RT_SPHERE_TEST(r1, base + h + 1)
-                            }
-#else
 #pragma unroll
                             for (int h = 0; h < RT_CLUSTER; h += 4) {
                                 const float4 r0 = cs[h], r1 = cs[h + 1], r2 = cs[h + 2], r3 = cs[h + 3];
@@ -567,7 +559,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                                 RT_SPHERE_TEST(r2, base + h + 2)
                                 RT_SPHERE_TEST(r3, base + h + 3)
                             }
-#endif
                         }
                         if (COUNT) c_clusters++;
                     }
