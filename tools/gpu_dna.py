@@ -15,3 +15,13 @@ for v in (0, 16):
 sc = rtmi.Scene.load(os.path.join(ROOT, "ray-tracing-in-cuda_amd/scenes/three_sphere.json")); sc.override(width=400, height=225, spp=100)
 st = rtmi.Stats(); sc.render(rtmi.Opts(seed=2023), st); sc.render(rtmi.Opts(seed=2023), st)
 print(f"three_sphere 400x225x100: {st.kernel_ms:.3f} ms -> {400*225*100/st.kernel_ms/1e3:.0f} Msamples/s")
+# where the DNA frame spends its time (diagnostic kernel sections)
+sc = rtmi.Scene.dna(0.0); sc.override(width=1280, height=720, spp=64)
+c = sc.count(rtmi.Opts(seed=2023)); d = c.as_dict(); cy = d["cycles"]; tot = sum(cy) or 1
+names = ["refill", "prefix spheres", "culled spheres/rects/cylinders", "shading", "accumulate", "loop control"]
+print("dna sections: " + ", ".join(f"{n} {100*v/tot:.1f}%" for n, v in zip(names, cy)), f"; queries/sample {d['queries']/d['samples']:.2f}, lanes/wave-query {d['queries']/max(1,d['wave_queries']):.1f}")
+for name in ("blue", "blue2"):
+    sc = rtmi.Scene.load(os.path.join(ROOT, f"tests/golden/scenes/{name}.json")); sc.override(width=1280, height=720, spp=256)
+    st = rtmi.Stats(); sc.render(rtmi.Opts(seed=2023), st); sc.render(rtmi.Opts(seed=2023), st)
+    info = sc.info
+    print(f"{name} 1280x720x256 ({info.num_prims} objects): {st.kernel_ms:.2f} ms -> {1280*720*256/st.kernel_ms/1e3:.0f} Msamples/s", flush=True)
