@@ -444,15 +444,15 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     }
     if (spp_chunk > sample_count) spp_chunk = sample_count;
     // Guided self-scheduling of the chunk-major queue: big chunks first, then chunks a quarter as long, then
-    // a sixteenth.  A launch ends when the last wave finishes its last item, and an item over glass and
-    // dense spheres costs about three times the average one, so the run of medium items has to last as
-    // long as a heavy big item (and the run of small items as long as a heavy medium one) for the other
-    // waves to have something to do meanwhile.  What that takes depends on r = resident waves / tiles:
-    // a whole 1080p frame (r = 0.19) gives up one big chunk, a 1/8 row shard (r = 1.5) five, plus five
-    // medium chunks cut into 4-sample items.  Measured (RTIOW 1080p x 1024 spp, one of N shards on one
-    // GPU vs whole / N): see tools/gpu_scale.py and DESIGN.md.  Only the lower lane occupancy of short
-    // items is paid, and only by the last few percent of the samples.
+    // a sixteenth.  A launch ends when the last wave finishes its last item; a 64-sample item takes ~3 ms of
+    // wall time (six waves share a SIMD) and an item over glass and dense spheres several times the average,
+    // so the runs of shorter items have to last long enough for the other waves to have something to do
+    // meanwhile.  How many big chunks are given up follows from r = resident waves / tiles: a whole 1080p
+    // frame (r = 0.19) gives up two of sixteen, a 1/8 row shard (r = 1.5) thirteen, of which thirteen
+    // quarter chunks are cut into 4-sample items.  Short items cost little since stragglers no longer
+    // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
     const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob: 0 = off
+    const double tail_factor = getenv("RTMI_TAIL_FACTOR") ? atof(getenv("RTMI_TAIL_FACTOR")) : 8.0;  // measured: 2 / 3 / 5 / 8 / 12 / 20 -> a 1/8 shard 34.8 / 34.0 / 33.5 / 32.5 / 32.8 / 33.0 ms
     int n_big = sample_count / spp_chunk, n_med = 0, q_med = spp_chunk, q_small = spp_chunk;
     int num_chunks;
     {
@@ -461,14 +461,14 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         const int rem = sample_count - n_big * spp_chunk;
         int rest = rem;  // samples after the big chunks
         if (tail_mode > 0 && spp_chunk >= 16 && n_big >= 1) {
-            const int n_split = std::min(n_big, std::max(1, (int)std::ceil(3.0 * r)));  // big chunks given up
+            const int n_split = std::min(n_big, std::max(1, (int)std::ceil(tail_factor * r)));  // big chunks given up
             n_big -= n_split;
             rest += n_split * spp_chunk;
             q_med = std::max(4, spp_chunk / 4);
             q_small = std::max(4, q_med / 4);
             int small_samples = 0;
             if (r >= 0.5 && q_small < q_med)  // few tiles per wave: a run of small items as well
-                small_samples = std::min(rest - q_med, std::max(1, (int)std::ceil(3.0 * r)) * q_med);
+                small_samples = std::min(rest - q_med, std::max(1, (int)std::ceil(tail_factor * r)) * q_med);
             if (small_samples < 0) small_samples = 0;
             n_med = (rest - small_samples) / q_med;  // whole medium chunks; the small run takes what is left
         } else {

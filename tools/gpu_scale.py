@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 rtmi = load_package()
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 sc = rtmi.Scene.rtiow(7, 1920, 1080, spp, 50)
 whole = None
 for n in (1, 2, 4, 8):
@@ -13,7 +14,7 @@ for n in (1, 2, 4, 8):
     for r in sorted({0, n - 1}):
         best = 1e9
         for rep in range(3):
-            st = rtmi.Stats(); sc.render(rtmi.Opts(seed=2023, tile_first=r, tile_stride=n), st); best = min(best, st.kernel_ms)
+            st = rtmi.Stats(); sc.render(rtmi.Opts(seed=2023, tile_first=r, tile_stride=n, spp_chunk=chunk), st); best = min(best, st.kernel_ms)
         ts.append(best)
     t = max(ts)
     if n == 1: whole = t
