@@ -567,12 +567,12 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     P.tiles_x = (s.width + 7) / 8;
     P.bands = (sh.local_rows + 7) / 8;
 
-    // LDS per workgroup: the hot tables (unless the variant reads them from global memory: bit 3) + two
-    // tile accumulators per wave.  The default kernel keeps the tables in LDS while that still leaves room
+    // LDS per workgroup: the hot tables (unless the variant reads them from global memory: bit 3) + one
+    // tile accumulator per wave.  The default kernel keeps the tables in LDS while that still leaves room
     // for the kernel's full occupancy (RT_WAVES_PER_SIMD workgroups per CU: RTIOW's 484 spheres 249 vs 253
     // ms); larger scenes run the same algorithm over global memory (variant 40: 1000 spheres 6.4 vs 6.9 ms,
     // 4000 spheres 20 vs 66 ms), which has no size limit.
-    const size_t acc_lds = 4 * 2 * 192 * sizeof(unsigned long long);
+    const size_t acc_lds = 4 * 192 * sizeof(unsigned long long);  // one 64-pixel rgb accumulator per wave
     const size_t hot_bytes = (size_t)P.hot_vec4 * 16;
     static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
                                                                              : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;

@@ -138,13 +138,13 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     // stage the hot tables (hittable_list contents) into LDS
     const int staged = SCALAR ? 0 : P.hot_vec4;
     for (int i = threadIdx.x; i < staged; i += 256) lds[i] = image[i];
-    // per-wave tile accumulators (two: current and older work item): 64 pixels x rgb, 64-bit fixed point
+    // per-wave tile accumulator of the current work item: 64 pixels x rgb, 64-bit fixed point
     unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + staged);
-    for (int i = threadIdx.x; i < 4 * 2 * 64 * 3; i += 256) tile_acc[i] = 0ull;
+    for (int i = threadIdx.x; i < 4 * 64 * 3; i += 256) tile_acc[i] = 0ull;
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long *my_acc = tile_acc + wave * 384;
+    unsigned long long *my_acc = tile_acc + wave * 192;
     const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
     const float4 *hot = SCALAR ? image : lds;
     const float4 *sph = hot;
@@ -177,20 +177,18 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
     // ---- persistent waves, streaming work items.  The grid only fills the chip; every wave pulls
     // (8x8 tile, sample chunk) work items from one global counter until it runs dry.  A wave does not
-    // drain an item before taking the next: when the pool of the CURRENT item is handed out, idle
-    // lanes start on the next item while the stragglers of the previous one (the OLDER item) finish;
-    // each of the two has its own tile accumulator in LDS, flushed when its last path ends.  So lanes
-    // only idle at the very end of the launch, and items can be short.  From here on the four waves
-    // of the workgroup never synchronise again.
-    unsigned long long *c_acc = my_acc;        // accumulator of the current item (wave-uniform pointers)
-    unsigned long long *o_acc = my_acc + 192;  //                 of the older item
+    // drain an item before taking the next: when the pool of the current item is handed out and a lane
+    // is idle, the item's tile accumulator (LDS) is flushed and the paths still alive finish as ORPHANS
+    // that add their sample straight to the global accumulators (integer sums: any split of an item's
+    // additions gives the same total).  So lanes only idle at the very end of the launch, and items can
+    // be short.  From here on the four waves of the workgroup never synchronise again.
+    unsigned long long *c_acc = my_acc;  // accumulator of the current item (wave-uniform pointer)
     int c_x0 = 0, c_band = 0, c_sbegin = 0, c_pool = 0, cursor = 0;  // c_pool = 64 x samples of the item
-    int o_tile = 0;  // older item: x0 | band << 16
-    bool c_valid = false, o_busy = false, queue_empty = false;
+    bool c_valid = false, queue_empty = false;
     int c_hy = 0, c_hvalid = 0;  // this lane's home pixel in the current item (row, on-image)
     int mine = 0;                // !POOL: samples of the home pixel started so far (current item)
-    // where this lane's live path adds its sample: -2 the current item's accumulator, -1 the older item's,
-    // >= 0 the path outlived its item (an orphan): local pixel index for a direct global add
+    // where this lane's live path adds its sample: -2 the current item's accumulator; >= 0 the path
+    // outlived its item (an orphan): dense local pixel index for a direct global add
     int slot = -2;
 
     // home pixel of this lane in the tile (x0, band): column, dense local row, image row, on-image
@@ -248,32 +246,15 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             if (POOL) exhausted = cursor >= c_pool;
             else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
         }
-        // The older item leaves its accumulator (the one flush site of the loop) when its last path has
-        // ended -- or when idle lanes need the slot for the next item while a few stragglers are still on
-        // long paths: what it has collected is flushed now, and those lanes become orphans that add their
-        // sample straight to the global accumulators when they finish (integer sums: any split of an
-        // item's additions gives the same total).  So idle lanes never wait for stragglers, however short
-        // the items are.
-        if (o_busy) {
-            const bool live_old = active && slot == -1;
-            const bool none_left = __builtin_amdgcn_ballot_w64(live_old) == 0ull;
-#ifdef RT_NO_ORPHANS
-            if (none_left) {
-#else
-            if (none_left || (idle != 0ull && exhausted && !queue_empty)) {
-#endif
-                const int o_x0 = o_tile & 0xffff, o_band = o_tile >> 16;
-                if (live_old) slot = (o_band * 8 + (cur_p >> 3)) * P.width + o_x0 + (cur_p & 7);  // dense local pixel index
-                flush_tile(o_acc, o_x0, o_band);
-                o_busy = false;
-            }
+        // The pool is handed out and idle lanes want the next item: retire the current one.  Its
+        // accumulator is flushed for reuse and every path still alive becomes an orphan.
+        if (c_valid && idle != 0ull && exhausted && !queue_empty) {
+            if (active && slot == -2) slot = (c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7);
+            flush_tile(c_acc, c_x0, c_band);
+            c_valid = false;
         }
         if (idle) {  // wave-uniform
-#ifdef RT_NO_ORPHANS
-            if (exhausted && !queue_empty && !(c_valid && o_busy)) {
-#else
             if (exhausted && !queue_empty) {
-#endif
                 unsigned int item = 0;
                 if (lane == 0) item = atomicAdd(queue, 1u);
                 item = __builtin_amdgcn_readfirstlane(item);
@@ -282,13 +263,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     queue_empty = true;  // the counter only grows: every wave gets here
                     if (COUNT) t_qe = __builtin_amdgcn_s_memrealtime();
                 } else {
-                    if (c_valid) {  // the current item becomes the older one; every live path is its
-                        o_tile = c_x0 | (c_band << 16);
-                        unsigned long long *t = c_acc;
-                        c_acc = o_acc, o_acc = t;
-                        o_busy = true;
-                        if (active && slot == -2) slot = -1;
-                    }
                     const unsigned int tiles_x = (unsigned int)ia.x, bands = (unsigned int)ia.y;
                     const int sample_first = ia.w, sample_count = ib.x, spp_chunk = ib.y;
                     const int n_big = ib.z, n_med = ib.w, q_med = ic.x, q_small = ic.y;
@@ -386,7 +360,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         }
         tick(0);
         if (!__any(active)) {
-            // nothing in flight (so the older item is already flushed).  Out of work when the queue is
+            // nothing in flight.  Out of work when the queue is
             // dry and the current item is handed out; otherwise loop: the refill above makes progress
             // every time (takes an item, marks the queue empty, or skips off-image pool entries).
             bool exhausted = !c_valid;
@@ -841,7 +815,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     atomicAdd(g + 1, radiance_to_fixed(L_g));
                     atomicAdd(g + 2, radiance_to_fixed(L_b));
                 } else {
-                    unsigned long long *a = (slot == -1 ? o_acc : c_acc) + cur_p * 3;
+                    unsigned long long *a = c_acc + cur_p * 3;
                     atomicAdd(a + 0, radiance_to_fixed(L_r));
                     atomicAdd(a + 1, radiance_to_fixed(L_g));
                     atomicAdd(a + 2, radiance_to_fixed(L_b));
