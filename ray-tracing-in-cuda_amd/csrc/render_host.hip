@@ -18,7 +18,7 @@
 #include "scene.hpp"
 
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 6
+#define RT_WAVES_PER_SIMD 7
 #endif
 namespace rtmi {
 
@@ -452,7 +452,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // quarter chunks are cut into 4-sample items.  Short items cost little since stragglers no longer
     // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
     const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob: 0 = off
-    const double tail_factor = getenv("RTMI_TAIL_FACTOR") ? atof(getenv("RTMI_TAIL_FACTOR")) : 8.0;  // measured: 2 / 3 / 5 / 8 / 12 / 20 -> a 1/8 shard 34.8 / 34.0 / 33.5 / 32.5 / 32.8 / 33.0 ms
+    const double tail_factor = getenv("RTMI_TAIL_FACTOR") ? atof(getenv("RTMI_TAIL_FACTOR")) : 12.0;  // measured at 7 waves/SIMD: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms, a 1/8 shard 33.7 / 33.4 / 32.0 / 32.2 ms
     int n_big = sample_count / spp_chunk, n_med = 0, q_med = spp_chunk, q_small = spp_chunk;
     int num_chunks;
     {

@@ -48,7 +48,7 @@
 
 // minimum resident waves per SIMD the register allocator must leave room for (8 <=> 64 VGPRs)
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 6
+#define RT_WAVES_PER_SIMD 7
 #endif
 
 namespace rtmi {
