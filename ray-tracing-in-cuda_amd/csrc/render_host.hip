@@ -445,10 +445,10 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     if (spp_chunk > sample_count) spp_chunk = sample_count;
     // Guided self-scheduling of the chunk-major queue: big chunks first, then chunks a quarter as long, then
     // a sixteenth.  A launch ends when the last wave finishes its last item; a 64-sample item takes ~3 ms of
-    // wall time (six waves share a SIMD) and an item over glass and dense spheres several times the average,
+    // wall time (seven waves share a SIMD) and an item over glass and dense spheres several times the average,
     // so the runs of shorter items have to last long enough for the other waves to have something to do
     // meanwhile.  How many big chunks are given up follows from r = resident waves / tiles: a whole 1080p
-    // frame (r = 0.19) gives up two of sixteen, a 1/8 row shard (r = 1.5) thirteen, of which thirteen
+    // frame (r = 0.22) gives up three of sixteen, a 1/8 row shard (r = 1.8) all sixteen, of which 22
     // quarter chunks are cut into 4-sample items.  Short items cost little since stragglers no longer
     // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
     const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob: 0 = off
