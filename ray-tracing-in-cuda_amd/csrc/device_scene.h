@@ -21,10 +21,6 @@
 #pragma once
 #include <stdint.h>
 
-// spheres per culling cluster (host packer and kernel agree on it)
-#ifndef RT_CLUSTER
-#define RT_CLUSTER 8
-#endif
 // consecutive clusters under one outer box
 #ifndef RT_GROUP
 #define RT_GROUP 4
@@ -72,6 +68,7 @@ struct RenderParams {
     int32_t ns_pad;          // sphere slots incl. never-hit padding (= ns)
     int32_t np;              // leading slots that are always tested (big spheres), multiple of 8
     int32_t ncl;             // clusters of 8 slots after the prefix, each with a bounding box
+    int32_t cluster;         // spheres per culling cluster (a multiple of 4, chosen per scene by the packer)
     int32_t off_box;         // 2 float4 per cluster: {min.xyz,_}, {max.xyz,_}
     int32_t ngr, off_gbox;   // outer boxes over RT_GROUP consecutive clusters
     int32_t nwin, off_wbox;  // window boxes over 64 consecutive clusters (64 / RT_GROUP outer boxes)

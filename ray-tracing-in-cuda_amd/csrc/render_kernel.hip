@@ -126,10 +126,11 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 // CULL:     after the always-tested big spheres, clusters of 8 spheres are visited only if some
 //           lane's ray passes the cluster's (inflated) bounding box: slab test of aabb.hpp:15-29
 //           + __any.  Conservative, so results are unchanged; fewer tests are executed.
+// CSIZE:    spheres per cluster (8 or 16: the packer picks per scene, RenderParams::cluster)
 //           2 (default): every lane collects the clusters ITS ray reaches in a bit mask and then walks its
 //           own list (per-lane LDS addresses), so a wave spends max-over-lanes instead of union-over-lanes
 //           cluster visits; 1: the whole wave visits every cluster some lane voted for; 0: no culling
-template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL>
+template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL, int CSIZE>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
                                                      unsigned int *__restrict__ queue,
@@ -522,11 +523,11 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         if (mine != 0ull) {
                             const int q = (int)__builtin_ctzll(mine);
                             mine &= mine - 1ull;
-                            const int base = P.np + RT_CLUSTER * (g0 * RT_GROUP + q);
+                            const int base = P.np + CSIZE * (g0 * RT_GROUP + q);
                             const float4 *cs = sph + base;
                             // four records at a time: eight in flight cost 20 spilled VGPRs at 6 waves/SIMD
 #pragma unroll
-                            for (int h = 0; h < RT_CLUSTER; h += 4) {
+                            for (int h = 0; h < CSIZE; h += 4) {
                                 const float4 r0 = cs[h], r1 = cs[h + 1], r2 = cs[h + 2], r3 = cs[h + 3];
                                 RT_SPHERE_TEST(r0, base + h)
                                 RT_SPHERE_TEST(r1, base + h + 1)
@@ -548,13 +549,16 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     const bool live = slab_live(box[2 * q], box[2 * q + 1]);
                     if (COUNT && live) c_lane_clusters++;
                     if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
-                        const int base = P.np + RT_CLUSTER * q;
+                        const int base = P.np + CSIZE * q;
                         const float4 *cs = sph + base;
-                        float4 rec[RT_CLUSTER];
 #pragma unroll
-                        for (int k = 0; k < RT_CLUSTER; ++k) rec[k] = cs[k];
-#pragma unroll
-                        for (int k = 0; k < RT_CLUSTER; ++k) RT_SPHERE_TEST(rec[k], base + k)
+                        for (int h = 0; h < CSIZE; h += 4) {
+                            const float4 r0 = cs[h], r1 = cs[h + 1], r2 = cs[h + 2], r3 = cs[h + 3];
+                            RT_SPHERE_TEST(r0, base + h)
+                            RT_SPHERE_TEST(r1, base + h + 1)
+                            RT_SPHERE_TEST(r2, base + h + 2)
+                            RT_SPHERE_TEST(r3, base + h + 3)
+                        }
                         blim = best_t * 1.0001f;
                         if (COUNT) c_clusters++;
                     }
@@ -895,19 +899,30 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
     X(24, true, true, true, 0)     \
     X(32, true, true, false, 1)    \
     X(40, true, true, true, 2)
+// every variant exists for both cluster sizes (the linear scans ignore it)
+#define RT_WITH_CSIZE(CALL8, CALL16) \
+    if (cluster == 16) { CALL16; } else { CALL8; }
+
 void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
                    DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
     const float4 *img = (const float4 *)image;
     const dim3 g(grid), t(256);
+    const int cluster = P.cluster;
     if (counters) {
-        if (variant == 40) hipLaunchKernelGGL((render_kernel<true, true, true, true, 2>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
-        else hipLaunchKernelGGL((render_kernel<true, true, true, false, 2>), g, t, lds_bytes, stream, P, img, acc, queue, counters);
+        if (variant == 40) {
+            RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<true, true, true, true, 2, 8>), g, t, lds_bytes, stream, P, img, acc, queue, counters),
+                          hipLaunchKernelGGL((render_kernel<true, true, true, true, 2, 16>), g, t, lds_bytes, stream, P, img, acc, queue, counters))
+        } else {
+            RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<true, true, true, false, 2, 8>), g, t, lds_bytes, stream, P, img, acc, queue, counters),
+                          hipLaunchKernelGGL((render_kernel<true, true, true, false, 2, 16>), g, t, lds_bytes, stream, P, img, acc, queue, counters))
+        }
         return;
     }
     DevCounters *none = nullptr;
-#define RT_LAUNCH(V, POOL, PRE, SCALAR, CULL)                                                          \
-    case V:                                                                                             \
-        hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL>), g, t, lds_bytes, stream, P, img, acc, queue, none); \
+#define RT_LAUNCH(V, POOL, PRE, SCALAR, CULL)                                                                                              \
+    case V:                                                                                                                                 \
+        RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 8>), g, t, lds_bytes, stream, P, img, acc, queue, none),  \
+                      hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 16>), g, t, lds_bytes, stream, P, img, acc, queue, none)) \
         break;
     switch (variant) {
         RT_VARIANT_TABLE(RT_LAUNCH)
@@ -918,15 +933,23 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
 
 // resident workgroups per CU of a variant at this dynamic-LDS size (advisory; an over-estimate only
 // leaves late workgroups that find the queue empty)
-int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes) {
+int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster) {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
     if (count) {
-        if (variant == 40) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, true, 2>, 256, lds_bytes);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, 2>, 256, lds_bytes);
+        if (variant == 40) {
+            RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, true, 2, 8>, 256, lds_bytes),
+                          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, true, 2, 16>, 256, lds_bytes))
+        } else {
+            RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, 2, 8>, 256, lds_bytes),
+                          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, 2, 16>, 256, lds_bytes))
+        }
     } else {
-#define RT_OCC(V, POOL, PRE, SCALAR, CULL) \
-    if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL>, 256, lds_bytes);
+#define RT_OCC(V, POOL, PRE, SCALAR, CULL)                                                                                                  \
+    if (variant == V) {                                                                                                                      \
+        RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL, 8>, 256, lds_bytes), \
+                      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL, 16>, 256, lds_bytes)) \
+    }
         RT_VARIANT_TABLE(RT_OCC)
 #undef RT_OCC
     }
@@ -960,15 +983,16 @@ void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStr
 }
 
 int set_max_dynamic_lds(size_t bytes) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<true, true, true, false, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-        return 1;
-#define RT_ATTR(V, POOL, PRE, SCALAR, CULL)                                                            \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<false, POOL, PRE, SCALAR, CULL>), \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)      \
-        return 1;
+#define RT_ATTR1(K)                                                                                                  \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+    RT_ATTR1((render_kernel<true, true, true, false, 2, 8>))
+    RT_ATTR1((render_kernel<true, true, true, false, 2, 16>))
+#define RT_ATTR(V, POOL, PRE, SCALAR, CULL)                      \
+    RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 8>)) \
+    RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 16>))
     RT_VARIANT_TABLE(RT_ATTR)
 #undef RT_ATTR
+#undef RT_ATTR1
     return 0;
 }
 

@@ -256,7 +256,7 @@ def test_scene_too_large_for_lds_uses_global_tables(rtmi, rtcheck):
     for i in range(20000):
         sc.sphere(rng.uniform(-10, 10, 3), float(rng.uniform(0.05, 0.2)), mats[i % len(mats)])
     st = sc.count(rtmi.Opts(seed=SEED))
-    assert st.cull_clusters > 64 * 30  # far more clusters than one 64-cluster window
+    assert st.cull_clusters > 64 * 10 and st.cull_clusters * st.cull_cluster_size >= 20000  # many 64-cluster windows
     _assert_same(rtmi, rtcheck, sc)
     small = rtmi.Scene.rtiow(7, 96, 54, 4, 50)
     assert np.array_equal(small.render(rtmi.Opts(seed=SEED, variant=40)), small.render(rtmi.Opts(seed=SEED)))
@@ -316,6 +316,37 @@ def test_axis_parallel_bounce_is_not_culled(rtmi, rtcheck):
         assert np.array_equal(rows[variant], rows[16])
 
 
+def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
+    """The packer clusters spheres on a sheet by 16 and spheres in a volume by 8 (both kernels are compiled);
+    RTMI_CLUSTER forces the other choice, which must not change a bit."""
+    for forced in ("8", "16"):
+        monkeypatch.setenv("RTMI_CLUSTER", forced)
+        sc = rtmi.Scene.rtiow(5, 120, 68, 5, 50)   # a sheet: 16 by default
+        st = sc.count(rtmi.Opts(seed=SEED))
+        assert st.cull_cluster_size == int(forced)
+        _assert_same(rtmi, rtcheck, sc)
+        _assert_same(rtmi, rtcheck, sc, variant=32)
+        vol = rtmi.Scene.new(64, 40, 3, 10)        # a volume: 8 by default
+        vol.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
+        vol.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
+        rng = np.random.default_rng(21)
+        mats = [vol.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(4)] + [vol.metal((0.8, 0.8, 0.8), 0.1), vol.dielectric(1.5)]
+        for i in range(300):
+            vol.sphere(rng.uniform(-4, 4, 3), float(rng.uniform(0.05, 0.3)), mats[i % len(mats)])
+        assert vol.count(rtmi.Opts(seed=SEED)).cull_cluster_size == int(forced)
+        _assert_same(rtmi, rtcheck, vol)
+        _assert_same(rtmi, rtcheck, vol, variant=40)
+    monkeypatch.delenv("RTMI_CLUSTER")
+    assert rtmi.Scene.rtiow(5, 32, 18, 1, 5).count(rtmi.Opts()).cull_cluster_size == 16
+    vol2 = rtmi.Scene.new(16, 16, 1, 3)
+    vol2.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
+    m = vol2.lambertian((0.5, 0.5, 0.5))
+    rng = np.random.default_rng(2)
+    for i in range(100):
+        vol2.sphere(rng.uniform(-4, 4, 3), 0.2, m)
+    assert vol2.count(rtmi.Opts()).cull_cluster_size == 8
+
+
 def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
     """AABB cluster culling vs the linear scan on the full frame, bit for bit.  Some paths leak
     ~2000 units inside the radius-1000 ground sphere, where the fp32 sphere test (|oc|^2 ~ 4e6,
@@ -334,7 +365,8 @@ def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
     st = sc.count(rtmi.Opts(seed=SEED))
     # the culled kernel really skips work: far fewer clusters visited than waves x clusters
     assert 0 < st.clusters_visited < 0.35 * st.wave_queries * st.cull_clusters
-    assert st.cull_prefix == 4 and st.cull_cluster_size == 8 and st.cull_clusters == 60
+    # RTIOW's small spheres lie on a sheet: the packer picks 16 per cluster (480 spheres -> 30 clusters)
+    assert st.cull_prefix == 4 and st.cull_cluster_size == 16 and st.cull_clusters == 30
     # a second scene seed, and the DNA frame (30 cylinders culled by their world-space boxes)
     sc2 = rtmi.Scene.rtiow(11, 960, 540, 16, 50)
     assert np.array_equal(sc2.render(rtmi.Opts(seed=3)), sc2.render(rtmi.Opts(seed=3, variant=16)))

@@ -28,6 +28,6 @@ for n in sizes:
     # a few rows against the linear scan (no culling): must be identical
     o = rtmi.Opts(seed=1, tile_rows=4, tile_first=60, tile_stride=100000)
     same = np.array_equal(sc.render(o), sc.render(rtmi.Opts(seed=1, tile_rows=4, tile_first=60, tile_stride=100000, variant=16))) if n <= 4000 else None
-    print(f"n={n}: {min(ts):.2f} ms ({W*H*SPP/min(ts)/1e3:.0f} Msamples/s), clusters {cst.cull_clusters}, "
+    print(f"n={n}: {min(ts):.2f} ms ({W*H*SPP/min(ts)/1e3:.0f} Msamples/s), clusters {cst.cull_clusters} x {cst.cull_cluster_size}, "
           f"wave cluster visits/query {cst.clusters_visited/max(1,cst.wave_queries):.1f}, groups passed/query {cst.groups_visited/max(1,cst.wave_queries):.1f}, "
           f"rows equal linear scan: {same}", flush=True)
