@@ -190,7 +190,9 @@ def main():
 
         # ---- roofline of the dominant kernel (rank 0's launch)
         roof = {"bound": "valu_fp32", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                "traffic": None}
+                "traffic": None,
+                "bound_note": "fp32 vector ALU (BASELINE.json metric and SURVEY 8(d): the path is not a contraction, "
+                              "so neither the MFMA nor the HBM roofline binds; HBM share below as hbm_frac)"}
         k_ms = float(np.mean(kernel_ms))
         roof["kernel_ms_avg"] = round(k_ms, 3)
         if not args.no_counts:
