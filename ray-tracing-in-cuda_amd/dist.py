@@ -48,22 +48,53 @@ def gather_framebuffer(local: torch.Tensor, scene, base: Opts, rank: int, world:
         rows = _rows_on(scene, base, 0, 1, local.device)
         full.index_copy_(0, rows, local[: len(rows)])
         return full
-    parts = None
     send = local.cpu() if via_host else local
+    big = None
+    parts = None
     if rank == dst:
-        parts = [torch.empty_like(send) for _ in range(world)]
+        # one receive buffer for all ranks (cached: the gather runs every step), gathered into as views
+        big = _recv_buffer(send, world)
+        parts = list(big.unbind(0))
     dist.gather(send, gather_list=parts, dst=dst, group=group)
     if rank != dst:
         return None
     if via_host:
-        parts = [p.to(local.device, non_blocking=True) for p in parts]
+        big = big.to(local.device, non_blocking=True)
     full = out if out is not None else torch.empty((scene.height, scene.width, 3), dtype=local.dtype,
                                                    device=local.device)
-    for r in range(world):
-        rows = _rows_on(scene, base, r, world, local.device)
-        if len(rows):
-            full.index_copy_(0, rows, parts[r][: len(rows)])
+    # one scatter for all shards: source rows (rank r's valid rows inside the padded receive buffer) -> image rows
+    src, dst_rows = _gather_indices(scene, base, world, local.shape[0], local.device)
+    full.index_copy_(0, dst_rows, big.view(-1, scene.width, 3).index_select(0, src))
     return full
+
+
+_RECV_CACHE: dict = {}
+
+
+def _recv_buffer(like: torch.Tensor, world: int) -> torch.Tensor:
+    key = (tuple(like.shape), like.dtype, str(like.device), world)
+    t = _RECV_CACHE.get(key)
+    if t is None:
+        t = torch.empty((world,) + tuple(like.shape), dtype=like.dtype, device=like.device)
+        _RECV_CACHE[key] = t
+    return t
+
+
+_INDEX_CACHE: dict = {}
+
+
+def _gather_indices(scene, base: Opts, world: int, padded_rows: int, device):
+    key = (id(scene), scene.height, base.tile_rows, world, padded_rows, str(device))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        src, dst_rows = [], []
+        for r in range(world):
+            rows = scene.shard_global_rows(shard_opts(base, r, world))
+            src.append(np.arange(len(rows), dtype=np.int64) + r * padded_rows)
+            dst_rows.append(np.asarray(rows, dtype=np.int64))
+        t = (torch.as_tensor(np.concatenate(src), device=device), torch.as_tensor(np.concatenate(dst_rows), device=device))
+        _INDEX_CACHE[key] = t
+    return t
 
 
 _ROWS_CACHE: dict = {}
