@@ -5,10 +5,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N rank processes itself (one per
+GPU, before this process touches the GPU) and fails if fewer than N devices are visible.
+
 One STEP = one full frame of the workload: every rank renders its interleaved row tiles
 with the HIP kernel (through the C ABI, into a torch tensor on torch's current stream),
-then ONE gather (RCCL over xGMI) assembles the framebuffer on rank 0.  Inputs (the scene
-image) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+then ONE gather (RCCL over xGMI) assembles the framebuffer on rank 0.  Nothing in a step waits on
+the host.  Inputs (the scene image) are resident in HBM before the timed region.  Rank 0 prints
+ONE JSON line.
 
 Workload (BASELINE.json configs[2], the configuration the north-star target is quoted on):
 RTIOW final random-spheres scene (rt_scene_rtiow(7): ~485 spheres, checker ground, defocus
@@ -17,18 +21,28 @@ split over N GPUs.
 
 metric   Msamples/s = W*H*spp / step seconds / 1e6          (whole job, all ranks)
 roofline fp32 vector ALU (not HBM, not MFMA: the path is a scalar-per-lane bounce loop).
-         achieved = algorithmic flops of one launch / mean kernel time (HIP events on the
-         launch stream, rt_stats.kernel_ms), flops from the accounting of DESIGN.md with
-         EXACT event counts from the diagnostic counting kernel;  peak 157.3 TFLOP/s.
-cpu_baseline  the reference's own cmake-cpu-version render() loop (oracle/_ref, "reference")
-         timed on this host's cores on a bounded sample of the same scene.
+         achieved = algorithmic flops of one launch / mean launch time (HIP events on the launch
+         stream around each timed step's render launches), flops from SURVEY.md 8(d)'s accounting
+         with EXACT event counts from the diagnostic counting kernel; peak 157.3 TFLOP/s.
+         `roofline` describes the default (culled) kernel as executed; `roofline_linear_scan` runs the
+         reference's O(N) hittable_list scan (variant 16) in the same invocation -- the algorithm 8(d)'s
+         accounting was written for.
+cpu_baseline  the reference's own cmake-cpu-version render() loop (oracle/_ref, "reference") on ALL of
+         this host's cores on a bounded sample of the same frame; plus the stock single-thread binary
+         and the fp32 restatement as `legs`.
+extra    the other BASELINE.json configurations (C1, C2b, C4's scene, one C5 shard), 2 steps each,
+         outside the headline timing.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,23 +52,27 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table: 256 CU x 4 SIMD x 32 lanes x 2 x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0
 
-# algorithmic flop accounting (DESIGN.md "flop accounting"):
-# add/sub/mul = 1, fma = 2, div/sqrt = 1, compares/selects/negations/integer RNG = 0
+# algorithmic flop accounting: add/sub/mul = 1, fma = 2, div/sqrt/rcp = 1,
+# compares/selects/min/max/negations/integer RNG = 0
 F_SAMPLE = 46          # jitter, camera ray, accumulate
-F_TEST = {0: 17, 1: 9, 2: 9, 3: 9, 4: 60}  # per ray-primitive test, by rt_prim_type
+F_TEST = {0: 17, 1: 9, 2: 9, 3: 9, 4: 60, 5: 40}  # per ray-primitive test, by rt_prim_type (5 = triangle)
 F_HIT = 30             # hit record of the accepted closest hit
 F_SCATTER = [40, 55, 65, 0]  # lambertian, metal, dielectric, diffuse_light
 F_MISS = 25            # sky / background evaluation
-F_BOX = 27             # slab test of one cluster box (6 sub, 6 mul, 6 min/max, 4 reduce, compare)
+F_BOX = 12             # slab test of one box: 6 fma (the min/max/compare that follow count 0)
+F_CULL_SETUP = 17      # per query: 3 reciprocals, margin (mul + add), 6 shifted origins (add + mul each)
+F_GRID_SETUP = 26      # per query of the grid walk: the above + entry point and per-axis step set-up (3 fma + 6 mul)
+F_GRID_STEP = 4        # per visited cell: one add on the stepped axis + the cell address (fma) -- the rest is compares
 
 
 def algorithmic_flops(counts: dict, prim_types) -> float:
+    """F = 46 S + sum_prims F_test * Q + 30 H + sum_m F_m B_m + 25 M  (T = queries x N)."""
     per_query = sum(F_TEST[int(t)] for t in prim_types)
     return (F_SAMPLE * counts["samples"] + per_query * counts["queries"] + F_HIT * counts["hits"]
             + sum(f * b for f, b in zip(F_SCATTER, counts["scatter"])) + F_MISS * counts["misses"])
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -68,12 +86,45 @@ def main():
     ap.add_argument("--seed", type=int, default=2023)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counts", action="store_true")
+    ap.add_argument("--no-linear", action="store_true", help="skip the linear-scan (variant 16) roofline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configurations")
     ap.add_argument("--cpu-spp", type=int, default=64)
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant (16 = linear scan without AABB culling)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (16 = linear scan without culling)")
     ap.add_argument("--verify", action="store_true", help="rank 0 also renders the unsharded frame and checks the "
                     "gathered one against it bit for bit (outside the timed region)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, so no
+    process that has initialised HIP is ever re-executed) and wait for them.  The parent never touches the GPU."""
+    import torch  # device_count() does not initialise the runtime on this image
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible: refusing to run on fewer "
+              f"(use --backend gloo to rehearse ranks that share a GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import numpy as np
     import torch
@@ -87,7 +138,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
@@ -105,20 +156,24 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     scene = rtmi.Scene.rtiow(7, args.width, args.height, args.spp, args.depth)
-    chunk = args.chunk if args.chunk >= 0 else default_chunk(args.spp)
+    chunk = args.chunk if args.chunk >= 0 else 0  # 0 = the library's default work-item size
     base = rtmi.Opts(seed=args.seed, device=dev_index, tile_rows=args.tile_rows, spp_chunk=chunk, variant=args.variant)
     mine = rdist.shard_opts(base, rank, world)
     local = rdist.alloc_local(scene, base, world, device)
     full = torch.empty((scene.height, scene.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
-    kernel_ms = []
+    via_host = args.backend != "nccl"
 
-    def step(record: bool):
-        st = rtmi.Stats()
-        scene.render_device(mine, local.data_ptr(), stream, st)
-        if record:
-            kernel_ms.append(st.kernel_ms)
-        return rdist.gather_framebuffer(local, scene, base, rank, world, out=full, via_host=args.backend != "nccl")
+    def step(events=None):
+        # HIP events on the stream the kernels are launched on; read after the timed loop (no host wait here)
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        scene.render_device(mine, local.data_ptr(), stream, None)
+        if events is not None:
+            e1.record()
+            events.append((e0, e1))
+        return rdist.gather_framebuffer(local, scene, base, rank, world, out=full, via_host=via_host)
 
     def barrier():
         if world > 1:
@@ -128,16 +183,14 @@ def main():
     # one-time set-up outside any timed or warm-up step: scene image upload, accumulator allocation and
     # occupancy query, and the communicator's first collective.  It is the same launch as a step, so that
     # every render_kernel row of a `rocprofv3 --stats` summary of this command is one step's launch.
-    prime = rdist.shard_opts(base, rank, world)
-    scene.render_device(prime, local.data_ptr(), stream, rtmi.Stats())
-    rdist.gather_framebuffer(local, scene, base, rank, world, out=full, via_host=args.backend != "nccl")
-
+    step()
     for _ in range(args.warmup):
-        step(False)
+        step()
     barrier()
+    events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        img = step(True)
+        img = step(events)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -147,6 +200,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
 
     samples_per_step = scene.width * scene.height * scene.spp
     ms_per_step = elapsed / args.steps * 1e3
@@ -187,81 +241,15 @@ def main():
         mean = float(img.mean().item()) / scene.spp
         result["config"]["frame_mean_radiance"] = round(mean, 5)
         assert np.isfinite(mean) and 0.2 < mean < 0.8, mean
-
-        # ---- roofline of the dominant kernel (rank 0's launch)
-        roof = {"bound": "valu_fp32", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                "traffic": None,
-                "bound_note": "fp32 vector ALU (BASELINE.json metric and SURVEY 8(d): the path is not a contraction, "
-                              "so neither the MFMA nor the HBM roofline binds; HBM share below as hbm_frac)"}
         k_ms = float(np.mean(kernel_ms))
-        roof["kernel_ms_avg"] = round(k_ms, 3)
-        if not args.no_counts:
-            st = scene.count(mine)  # exact event counts of rank 0's shard (same seed, same samples; culled kernel)
-            c = st.as_dict()
-            linear_flops = algorithmic_flops(c, scene.prims()["type"])
-            # the ray-primitive tests the kernel executes, counted per LANE (one ray against one sphere or box):
-            # every live lane tests the always-tested prefix, every outer box, the cluster boxes of the outer
-            # boxes some lane of its wave passed, and the spheres of the clusters ITS OWN ray reaches
-            wq = c["wave_queries"]
-            lanes = c["queries"] / max(1, wq)  # live lanes per wave-level query
-            culled = args.variant & 16 == 0
-            if culled:
-                sphere_tests = c["queries"] * c["cull_prefix"] + c["lane_clusters"] * c["cull_cluster_size"]
-                box_tests = c["queries"] * c["cull_groups"] + lanes * c["groups_visited"] * 4
-            else:
-                sphere_tests = c["queries"] * (c["cull_prefix"] + c["cull_clusters"] * c["cull_cluster_size"])
-                box_tests = 0
-            per_query_linear = sum(F_TEST[int(t)] for t in scene.prims()["type"])
-            flops = 17 * sphere_tests + F_BOX * box_tests + linear_flops - per_query_linear * c["queries"]
-            roof["mode"] = "aabb-culled hittable_list, per-lane cluster lists (default)" if culled else "linear hittable_list scan (variant 16)"
-            if args.variant in (8, 32):  # the diagnostic kernel is the default one: its counts do not describe these
-                roof["mode"] = "ablation variant with wave-level cluster votes: no flop count"
-                flops = 0
-            roof["achieved"] = round(flops / (k_ms * 1e-3) / 1e12, 3) if flops else None
-            roof["frac"] = round(roof["achieved"] / PEAK_FP32_TFLOPS, 4) if flops else None
-            roof["flops_per_launch"] = int(flops)
-            roof["accounting"] = ("flops = 46 S + 17 T_sphere + 27 T_box + 30 H + 40/55/65 B + 25 M with the sphere and "
-                                  "box tests the kernel's lanes execute (masked-off lanes not counted), all counted "
-                                  "exactly by the diagnostic kernel")
-            roof["counts"] = {k: c[k] for k in ("samples", "queries", "prim_tests", "hits", "misses", "scatter",
-                                                "rng_draws", "wave_queries", "clusters_visited", "groups_visited",
-                                                "lane_clusters", "lane_groups")}
-            roof["tests_per_sample"] = {"sphere": round(sphere_tests / max(1, c["samples"]), 1),
-                                        "box": round(box_tests / max(1, c["samples"]), 1),
-                                        "reference_linear_scan": round(c["prim_tests"] / max(1, c["samples"]), 1)}
-            roof["lane_occupancy_of_queries"] = round(c["queries"] / max(1, 64 * wq), 4)
-            # for comparison only: what the reference's O(N) scan (T = queries x N) would have
-            # to sustain to render the same frame in the same time
-            roof["reference_linear_scan_equivalent"] = {
-                "tflops": round(linear_flops / (k_ms * 1e-3) / 1e12, 3),
-                "frac_of_peak": round(linear_flops / (k_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)}
-            roof["valu_issue_peak_Tlane_inst"] = 78.6
-        # algorithmic HBM bytes: framebuffer write once + scene image read once per workgroup (L2-resident)
-        rows0 = scene.shard_rows(mine)
-        plane = rows0 * scene.width * 3
-        n_chunks = -(-scene.spp // (chunk or 64))
-        # per launch: clear the 64-bit accumulators, one 8-byte atomic per pixel-channel and work item,
-        # read them back and write the fp32 frame
-        algo_bytes = plane * (8 + 8 * n_chunks + 8 + 4)
-        roof["hbm_algorithmic_bytes"] = int(algo_bytes)
-        roof["hbm_achieved_GBps"] = round(algo_bytes / (k_ms * 1e-3) / 1e9, 3)
-        roof["hbm_frac"] = round(roof["hbm_achieved_GBps"] / PEAK_HBM_GBPS, 6)
-        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tf = json.load(open(traffic_file))
-                key = f"{scene.width}x{scene.height}x{scene.spp}"
-                if key in tf:
-                    roof["traffic"] = tf[key]["bytes_per_launch"]
-                    roof["traffic_source"] = tf[key].get("source")
-            except Exception:
-                pass
-        result["roofline"] = roof
-
+        result["roofline"] = roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np)
+        if world == 1 and not args.no_linear and not args.no_counts and args.variant == 0:
+            result["roofline_linear_scan"] = linear_scan_leg(rtmi, scene, base, local, stream, torch, np)
+        if world == 1 and not args.no_extra:
+            result["extra"] = extra_configs(rtmi, dev_index, args.seed, local, stream, torch, np)
         # ---- CPU baseline (reported only): the reference's own render() on this host's cores
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(rtmi, args)
-
         print(json.dumps(result), flush=True)
 
     if world > 1:
@@ -269,44 +257,277 @@ def main():
         dist.destroy_process_group()
 
 
-def default_chunk(spp: int) -> int:
-    """Samples per work item (8x8 tile x chunk, one wave): 0 = the library default (64).
-    Scheduling only -- the fixed-point pixel sums do not depend on it."""
-    return 0
+def _git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
+    """fp32-ALU roofline of the dominant kernel (rank 0's launch)."""
+    roof = {"bound": "valu_fp32", "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None,
+            "traffic": None,
+            "bound_note": "fp32 vector ALU (BASELINE.json metric and SURVEY 8(d): the path is not a contraction, "
+                          "so neither the MFMA nor the HBM roofline binds; HBM share below as hbm_frac)",
+            "kernel_ms_avg": round(k_ms, 3),
+            "kernel_ms_note": "HIP events on the launch stream around each timed step's launches (accumulator clear, "
+                              "render_kernel, finalize)"}
+    if not args.no_counts:
+        st = scene.count(mine)  # exact event counts of rank 0's shard (same seed, same samples; culled kernel)
+        c = st.as_dict()
+        types = scene.prims()["type"]
+        linear_flops = algorithmic_flops(c, types)
+        per_query_linear = sum(F_TEST[int(t)] for t in types)
+        n_other = sum(F_TEST[int(t)] for t in types if int(t) != 0)  # rects / cylinders / triangles: tested per query
+        culled = args.variant & 16 == 0
+        wq = max(1, c["wave_queries"])
+        lanes = c["queries"] / wq  # live lanes per wave-level query
+        if culled:
+            sphere_tests, box_tests, setup = executed_tests(c, lanes)
+        else:
+            sphere_tests = c["queries"] * (c["cull_prefix"] + c["cull_clusters"] * c["cull_cluster_size"])
+            box_tests, setup = 0, 0.0
+        shading = linear_flops - per_query_linear * c["queries"]  # 46 S + 30 H + scatter + 25 M
+        flops_strict = 17 * sphere_tests + n_other * c["queries"] + shading            # box tests = accelerator overhead
+        flops = flops_strict + F_BOX * box_tests + setup
+        roof["mode"] = ("culled hittable_list (default kernel)" if culled else "linear hittable_list scan (variant 16)")
+        if args.variant in (8, 32):  # the diagnostic kernel is the default one: its counts do not describe these
+            roof["mode"] = "ablation variant with wave-level cluster votes: no flop count"
+            flops = flops_strict = 0
+        if flops:
+            roof["achieved"] = round(flops / (k_ms * 1e-3) / 1e12, 3)
+            roof["frac"] = round(roof["achieved"] / PEAK_FP32_TFLOPS, 4)
+            roof["frac_excluding_box_tests"] = round(flops_strict / (k_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)
+        roof["flops_per_launch"] = int(flops)
+        roof["accounting"] = ("SURVEY 8(d): flops = 46 S + 17 T_sphere + 12 T_box (6 fma; min/max/compare = 0) + per-query "
+                              "culling set-up + 30 H + 40/55/65 B + 25 M, with the sphere and box tests the kernel's lanes "
+                              "EXECUTE (masked-off lanes not counted), all counted exactly by the diagnostic kernel; "
+                              "frac_excluding_box_tests counts the accelerator's own work as 0")
+        roof["counts"] = {k: c[k] for k in ("samples", "queries", "prim_tests", "hits", "misses", "scatter",
+                                            "rng_draws", "wave_queries", "clusters_visited", "groups_visited",
+                                            "lane_clusters", "lane_groups") if k in c}
+        roof["tests_per_sample"] = {"sphere": round(sphere_tests / max(1, c["samples"]), 1),
+                                    "box": round(box_tests / max(1, c["samples"]), 1),
+                                    "reference_linear_scan": round(c["prim_tests"] / max(1, c["samples"]), 1)}
+        roof["lane_occupancy_of_queries"] = round(c["queries"] / max(1, 64 * wq), 4)
+        roof["valu_issue_peak_Tlane_inst"] = 78.6
+    # HBM: SURVEY 8(d)'s algorithmic bytes are ONE framebuffer of W x H x 16 B; the kernel's own minimum adds the
+    # 64-bit accumulator plane (clear, one flush per work item, read-back)
+    rows0 = scene.shard_rows(mine)
+    plane = rows0 * scene.width * 3
+    n_chunks = -(-scene.spp // (chunk or 64))
+    algo_bytes = plane * (8 + 8 * n_chunks + 8 + 4)
+    roof["hbm_survey_bytes"] = int(rows0 * scene.width * 16)
+    roof["hbm_algorithmic_bytes"] = int(algo_bytes)
+    roof["hbm_achieved_GBps"] = round(algo_bytes / (k_ms * 1e-3) / 1e9, 3)
+    roof["hbm_frac"] = round(roof["hbm_achieved_GBps"] / PEAK_HBM_GBPS, 6)
+    # measured HBM traffic: rocprofv3 PMC passes (tools/profile.sh) of THIS command line, kept under profiles/;
+    # static (not collected in this run), so only quoted when workload, variant, chunk and world match the profiled run
+    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(traffic_file) and world == 1 and args.variant == 0 and chunk == 0:
+        try:
+            tf = json.load(open(traffic_file))
+            key = f"{scene.width}x{scene.height}x{scene.spp}"
+            if key in tf:
+                roof["traffic"] = tf[key]["bytes_per_launch"]
+                roof["traffic_ratio_vs_survey_bytes"] = round(tf[key]["bytes_per_launch"] / roof["hbm_survey_bytes"], 2)
+                roof["traffic_source"] = {"kind": "static: PMC passes of this command, not re-collected in this run",
+                                          "file": "profiles/hbm_traffic.json", "detail": tf[key].get("source"),
+                                          "profiled_at_head": tf[key].get("head"), "this_head": _git_head()}
+        except Exception:
+            pass
+    return roof
+
+
+def executed_tests(c: dict, lanes: float):
+    """Ray-primitive and box tests the default kernel's lanes execute, from the diagnostic counters.
+    Returns (sphere tests, box tests, per-query set-up flops)."""
+    q = c["queries"]
+    if c.get("grid_cells", 0) or c.get("cull_grid", 0):
+        # grid walk: prefix spheres for every query, one scene-box test per query, then per visited cell its spheres
+        sphere_tests = q * c["cull_prefix"] + c["grid_tests"]
+        box_tests = q  # the grid's bounding box
+        setup = F_GRID_SETUP * q + F_GRID_STEP * c["grid_cells"]
+        return sphere_tests, box_tests, setup
+    # cluster boxes: every live lane tests the always-tested prefix, every outer box, the cluster boxes of the outer
+    # boxes some lane of its wave passed, and the spheres of the clusters ITS OWN ray reaches
+    sphere_tests = q * c["cull_prefix"] + c["lane_clusters"] * c["cull_cluster_size"]
+    box_tests = q * c["cull_groups"] + lanes * c["groups_visited"] * 4
+    return sphere_tests, box_tests, F_CULL_SETUP * q
+
+
+def _timed_launches(scene, opts, local, stream, torch, steps):
+    """mean launch time (ms) of `steps` renders after one untimed one, HIP events on the launch stream"""
+    scene.render_device(opts, local.data_ptr(), stream, None)
+    ev = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        scene.render_device(opts, local.data_ptr(), stream, None)
+        b.record()
+        ev.append((a, b))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+
+def linear_scan_leg(rtmi, scene, base, local, stream, torch, np, steps=2):
+    """SURVEY 8(d)'s literal accounting on the algorithm it was written for: the reference's linear
+    hittable_list scan (rt_opts.variant 16: every sphere tested for every query), same frame, same seed,
+    bit-identical framebuffer."""
+    o = rtmi.Opts(seed=base.seed, device=base.device, tile_rows=base.tile_rows, spp_chunk=base.spp_chunk, variant=16)
+    ms = _timed_launches(scene, o, local, stream, torch, steps)
+    c = scene.count(rtmi.Opts(seed=base.seed, device=base.device, tile_rows=base.tile_rows)).as_dict()
+    flops = algorithmic_flops(c, scene.prims()["type"])  # T = queries x N, nothing else
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel_variant": 16, "steps": steps, "kernel_ms": round(ms, 3),
+            "Msamples_per_s": round(scene.width * scene.height * scene.spp / (ms * 1e-3) / 1e6, 1),
+            "flops_per_launch": int(flops), "achieved": round(tf, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+            "accounting": "46 S + 17 (queries x N spheres) + 30 H + 40/55/65 B + 25 M; the kernel also executes the "
+                          "table's padding slots, which are not counted"}
+
+
+def extra_configs(rtmi, dev, seed, scratch, stream, torch, np, steps=2):
+    """The other BASELINE.json configurations on this GPU, outside the headline timing: mean launch time of
+    `steps` launches each (HIP events), whole frame unless stated."""
+    out = {}
+    scenes_dir = os.path.join(ROOT, "ray-tracing-in-cuda_amd", "scenes")
+    golden = os.path.join(ROOT, "tests", "golden", "scenes")
+
+    def run(name, sc, opts, what):
+        rows = sc.shard_rows(opts)
+        buf = torch.empty((rows, sc.width, 3), dtype=torch.float32, device=scratch.device)
+        ms = _timed_launches(sc, opts, buf, stream, torch, steps)
+        n = rows * sc.width * sc.spp
+        out[name] = {"workload": what, "kernel_ms": round(ms, 3), "Msamples_per_s": round(n / (ms * 1e-3) / 1e6, 1),
+                     "samples": n, "steps": steps}
+
+    c1 = rtmi.Scene.load(os.path.join(scenes_dir, "three_sphere.json"))
+    c1.override(width=400, height=225, spp=100, max_depth=50)
+    run("config1_three_sphere", c1, rtmi.Opts(seed=seed, device=dev), "3-sphere scene 400x225, 100 spp, depth 50")
+    c2 = rtmi.Scene.dna(0.0)
+    c2.override(width=1280, height=720, spp=256, max_depth=50)
+    run("config2b_dna", c2, rtmi.Opts(seed=seed, device=dev),
+        "basic_scene.json filled with dna.py frame 0 (60 emissive spheres + 30 emissive cylinders), 1280x720, 256 spp")
+    c4 = rtmi.Scene.load(os.path.join(golden, "sample_scene.json"))
+    c4.override(width=1920, height=1080, spp=512, max_depth=50)
+    run("config4_sample_scene", c4, rtmi.Opts(seed=seed, device=dev),
+        "sample_scene.json 1920x1080 at 512 of its 4096 spp (cost per sample does not depend on spp), whole frame")
+    c5 = rtmi.Scene.rtiow(7, 3840, 2160, 8192, 50)
+    run("config5_one_of_8_shards", c5, rtmi.Opts(seed=seed, device=dev, tile_first=0, tile_stride=8),
+        "RTIOW 3840x2160, 8192 spp: rank 0's row tiles of the 8-GPU split (1/8 of the frame) on this GPU")
+    return out
+
+
+def cgroup_cpu_quota():
+    """CPU quota of this container in cores (cgroup v2 cpu.max, v1 cfs quota), None when unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
 
 
 def cpu_baseline(rtmi, args):
+    """Reported-only baseline, SURVEY 8(d): (ii) the reference's render() on all host cores [the headline `value`],
+    (i) the stock single-thread binary, (iii) the fp32 restatement -- each on a bounded sample."""
+    import ctypes as C
     import rtcheck
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    affinity = len(os.sched_getaffinity(0))
+    nproc = os.cpu_count()
+    quota = cgroup_cpu_quota()
+    # threads = the cores this process may actually use: its affinity mask, capped by the container's CPU quota
+    # (a box may show every core of the host and still be throttled to a share of them)
+    cores = affinity if quota is None else max(1, min(affinity, int(quota + 0.999)))
     spp = args.cpu_spp
+    period, band = 32, 8
     sc = rtmi.Scene.rtiow(7, args.width, args.height, spp, args.depth)
-    # bounded sample: every 4th band of 8 rows of the full-size frame at reduced spp
-    # (cost per sample does not depend on spp); ~4 M samples
-    bands = [(y, min(y + 8, args.height)) for y in range(0, args.height, 32)]
-    n_samples = sum((b - a) for a, b in bands) * args.width * spp
+    legs = {}
+    # bounded sample: every 4th band of 8 rows of the full-size frame at reduced spp (cost per sample does not
+    # depend on spp).  Systematic in y, so sky, spheres and ground are represented in the frame's proportions.
+    what = None
     if rtcheck.have_ref():
+        lib = rtcheck.ref_lib()
+        lib.ref_time_sample.restype = C.c_double
+        lib.ref_time_sample.argtypes = [C.c_void_p, C.c_uint64] + [C.c_int] * 9 + [C.POINTER(C.c_double),
+                                                                                  C.POINTER(C.c_longlong)]
         rs = rtcheck.RefScene(sc)
-        sec = 0.0
-        for a, b in bands:
-            s, _ = rs.time_rows(args.seed, a, b, spp, threads=cores)
-            sec += s
+        chk, px = C.c_double(), C.c_longlong()
+        # sampling error: the same estimator on the three other phases of the systematic sample at 1/8 of the spp
+        sec = lib.ref_time_sample(rs.h, args.seed, args.width, args.height, 0, args.height, period, band, spp,
+                                  args.depth, cores, C.byref(chk), C.byref(px))
+        n_samples = px.value * spp
+        rate = n_samples / sec / 1e6
+        phase_rates = []
+        for ph in (8, 16, 24):
+            s2 = lib.ref_time_sample(rs.h, args.seed, args.width, args.height, ph, args.height, period, band,
+                                     max(1, spp // 8), args.depth, cores, C.byref(chk), C.byref(px))
+            phase_rates.append(px.value * max(1, spp // 8) / s2 / 1e6)
+        spread = (max(phase_rates + [rate]) - min(phase_rates + [rate])) / rate
         kind = "reference"
-        what = "cmake-cpu-version render() per pixel (oracle/_ref: the reference's sources + hooked rand())"
+        what = ("cmake-cpu-version render() per pixel (oracle/_ref: the reference's own sources + hooked rand()), "
+                f"OpenMP over (row, 64-pixel span) on {cores} threads")
+        legs["ii_reference_all_cores"] = {"Msamples_per_s": round(rate, 4), "threads": cores, "seconds": round(sec, 2),
+                                         "samples": n_samples,
+                                         "sampling_spread": round(spread, 4),
+                                         "sampling_note": "max-min over the four phases of the every-4th-band sample, "
+                                                          "relative (the other three phases at 1/8 of the spp)"}
+        stock = os.path.join(ROOT, "oracle", "_ref", "ref_stock")
+        if os.path.exists(stock):
+            try:
+                w1, h1 = 960, 540
+                with tempfile.TemporaryDirectory() as td:
+                    subprocess.run([stock, "-w", str(w1), "-h", str(h1), "-spp", "1", "-d", str(args.depth)], cwd=td,
+                                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+                    log = open(os.path.join(td, "gpu-version-time.log")).read()
+                m = re.search(r"time:\s*([0-9.eE+-]+)\s*s", log)
+                t1 = float(m.group(1))
+                legs["i_stock_single_thread"] = {
+                    "Msamples_per_s_per_core": round(w1 * h1 / t1 / 1e6, 4), "seconds": round(t1, 2),
+                    "what": f"cmake-cpu-version/main.cpp as shipped (-DMT_RANDOM_GENERATOR, its own random_scene and "
+                            f"mt19937 stream, one thread, whole program incl. PPM text output), {w1}x{h1}, 1 spp, "
+                            f"time from its own log line"}
+            except Exception as e:  # the leg is optional: never lose the bench line over it
+                legs["i_stock_single_thread"] = {"error": repr(e)}
     else:
-        osc = rtcheck.OracleScene(sc)
-        t0 = time.perf_counter()
-        for a, b in bands:
-            rtcheck.oracle_render(osc, seed=args.seed, rows=(a, b), threads=cores)
-        sec = time.perf_counter() - t0
         kind = "port"
-        what = "fp32 CPU restatement (oracle/rt_oracle.c)"
+    # (iii) the restatement (oracle/rt_oracle.c), same sample
+    try:
+        olib = rtcheck.oracle_lib()
+        olib.rto_time_sample.restype = C.c_double
+        olib.rto_time_sample.argtypes = [C.c_void_p, C.c_uint64] + [C.c_int] * 6 + [C.POINTER(C.c_double),
+                                                                                    C.POINTER(C.c_longlong)]
+        osc = rtcheck.OracleScene(sc)
+        chk, px = C.c_double(), C.c_longlong()
+        sec3 = olib.rto_time_sample(C.cast(C.byref(osc.c), C.c_void_p), args.seed, 0, args.height, period, band, spp,
+                                    cores, C.byref(chk), C.byref(px))
+        legs["iii_restatement_all_cores"] = {"Msamples_per_s": round(px.value * spp / sec3 / 1e6, 4), "threads": cores,
+                                             "seconds": round(sec3, 2),
+                                             "what": "fp32 restatement oracle/rt_oracle.c, same sample"}
+        if kind == "port":
+            rate, sec, n_samples = px.value * spp / sec3 / 1e6, sec3, px.value * spp
+            what = f"fp32 CPU restatement (oracle/rt_oracle.c), OpenMP on {cores} threads"
+    except Exception as e:
+        legs["iii_restatement_all_cores"] = {"error": repr(e)}
     return {
-        "value": round(n_samples / sec / 1e6, 4),
+        "value": round(rate, 4),
         "unit": "Msamples/s",
         "cores": cores,
+        "nproc": nproc,
+        "affinity_cores": affinity,
+        "cgroup_cpu_quota": quota,
         "kind": kind,
         "sample": f"{what}; same scene at {args.width}x{args.height}, every 4th 8-row band, {spp} spp "
-                  f"({n_samples} samples, {sec:.1f} s, OpenMP over rows)",
+                  f"({n_samples} samples, {sec:.1f} s)",
+        "legs": legs,
     }
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 1
+#define RTMI_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -249,6 +249,11 @@ typedef struct rt_stats {
     int32_t cull_prefix, cull_clusters, cull_groups, cull_cluster_size; /* table geometry */
     double wave_start_spread_us, wave_end_spread_us, wave_span_us; /* first-to-last wave start / exit, first start
                                         to last exit (s_memrealtime) */
+    /* rt_render_hip_tiles only: kernel_ms above is the SLOWEST device's render launches */
+    double gather_ms;     /* root device: end of its own render -> assembled frame (ncclGather + row placement,
+                             includes waiting for slower peers) */
+    int32_t devices_used;
+    int32_t reserved_;
 } rt_stats;
 
 void rt_opts_default(rt_opts *o);
@@ -272,6 +277,19 @@ int rt_render_hip_device(const rt_scene *s, const rt_opts *o, void *d_rgb_sum, v
 /* same, host buffer in / out: allocates, launches, copies back, frees
  * (main.cu:482-513: cudaMallocManaged + render + cudaDeviceSynchronize). */
 int rt_render_hip(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_stats *stats);
+
+/* One frame on n_devices GPUs of this node (SURVEY.md 8(b) "Threading", 8(e); the reference's only multi-GPU
+ * mechanism is one renderer process per GPU per animation FRAME, gpu-version/blue.py:23-32).  Row tile t
+ * (o->tile_rows rows, default 8) is rendered by devices[t mod n] on a stream of its own -- the launch
+ * rt_render_hip_device makes for that shard -- then ONE ncclGather (rccl.h:745, root = devices[0]) collects the
+ * dense local buffers and a kernel on the root places the rows; rgb_sum (host, H*W*3 floats) receives the frame.
+ * The result is bit-identical to rt_render_hip for every n.  devices == NULL means ordinals 0..n-1; the list must
+ * not repeat a device.  o->device, tile_first and tile_stride are ignored (the call sets them per device).
+ * Streams, RCCL communicators (ncclCommInitAll, ~0.1 s once per device list) and buffers are kept between calls;
+ * rt_tiles_shutdown() releases them.  RCCL is loaded with dlopen at the first call: librtmi.so does not link it. */
+int rt_render_hip_tiles(const rt_scene *s, const rt_opts *o, const int *devices, int n_devices,
+                        float *rgb_sum, rt_stats *stats);
+void rt_tiles_shutdown(void);
 
 /* diagnostic launch of the same kernel with exact event counters (samples,
  * hit queries, primitive tests, ...) for the roofline's algorithmic flops.
@@ -298,6 +316,13 @@ void rt_acc_to_rgb(const int64_t *acc, float *rgb_sum, size_t n_values);
 int rt_shard_scatter_rows(const rt_scene *s, const rt_opts *o, const float *local_rgb,
                           float *full_rgb);
 
+/* the same on the device, for a GATHERED buffer: d_gathered[n_ranks][pad_rows][W][3] holds rank r's dense local
+ * rows (tile t of the frame = local tile t / n_ranks of rank t mod n_ranks; pad_rows >= the largest shard), as
+ * ncclGather delivers them; one kernel on `stream` (hipStream_t as void*) writes d_full[H][W][3].
+ * rt_render_hip_tiles uses it on its root device. */
+int rt_shard_place_rows_device(const rt_scene *s, const rt_opts *o, int n_ranks, int pad_rows,
+                               const void *d_gathered, void *d_full, void *stream);
+
 /* ---- output ------------------------------------------------------------ */
 
 /* output_image(), gpu-version/main.cu:359-372 + write_color color.cuh:70-95:
@@ -319,6 +344,9 @@ const char *rt_scene_output_file(const rt_scene *s);
 const char *rt_last_error(void);
 const char *rt_status_string(int status);
 int rt_abi_version(void);
+/* sizeof of the ABI structs as this library was compiled (binding self-checks):
+ * 0 rt_opts, 1 rt_stats, 2 rt_prim, 3 rt_material, 4 rt_texture, 5 rt_camera, 6 rt_scene_info; else 0 */
+size_t rt_struct_size(int which);
 /* number of usable gfx950 devices, or -rt_status */
 int rt_device_count(void);
 /* Philox4x32-10 block (seeds every (pixel, sample) stream), for known-answer tests */

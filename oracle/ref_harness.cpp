@@ -217,6 +217,45 @@ double ref_time_rows(void *h, uint64_t seed, int width, int height, int y0, int 
 #endif
 }
 
+// The CPU baseline's bounded sample: the reference's render() on rows y with ((y - y0) % period) < band,
+// y in [y0, y1) -- every period-th band of `band` rows of the full-size frame.  One parallel loop over
+// (row, 64-pixel span) so that every host core has work whatever the band height.
+double ref_time_sample(void *h, uint64_t seed, int width, int height, int y0, int y1, int period, int band, int spp,
+                       int max_depth, int threads, double *checksum, long long *pixels) {
+    RefScene *s = (RefScene *)h;
+    if (!s || !s->cam || period <= 0 || band <= 0) return -1.0;
+    std::vector<int> rows;
+    for (int y = y0; y < y1; ++y)
+        if ((y - y0) % period < band) rows.push_back(y);
+    const int spans = (width + 63) / 64;
+    const long long jobs = (long long)rows.size() * spans;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+    double t0 = omp_get_wtime();
+#else
+    threads = 1;
+    clock_t c0 = clock();
+#endif
+    double acc = 0.0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : acc)
+    for (long long j = 0; j < jobs; ++j) {
+        const int y = rows[(size_t)(j / spans)];
+        const int xa = (int)(j % spans) * 64, xb = std::min(width, xa + 64);
+        for (int x = xa; x < xb; ++x) {
+            hook_seed(seed, (uint32_t)(y * width + x), 0u);
+            color c = render((double)x, (double)y, spp, *s->cam, s->world, max_depth, width, height);
+            acc += c.x() + c.y() + c.z();
+        }
+    }
+    if (checksum) *checksum = acc;
+    if (pixels) *pixels = (long long)rows.size() * width;
+#ifdef _OPENMP
+    return omp_get_wtime() - t0;
+#else
+    return (double)(clock() - c0) / CLOCKS_PER_SEC;
+#endif
+}
+
 // the reference's write_color(out, c, spp) (color.h:14-35) for one pixel: the three
 // integers it prints to the PPM
 void ref_write_color(const double rgb_sum[3], int spp, int out[3]) {

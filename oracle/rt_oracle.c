@@ -36,6 +36,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -595,13 +596,15 @@ static uint64_t radiance_to_fixed(float v) {
 }
 static float fixed_to_sum(uint64_t t) { return (float)((double)(int64_t)t * (1.0 / 4294967296.0)); }
 
-/* render() per pixel, cpu/main.cpp:45-55, over the pixel loop of :99-106.
- * spp_chunk is accepted for interface symmetry with rt_opts and has no effect on the
- * result (the sum is exact). */
-int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_first,
-               int sample_count, int spp_chunk, float *rgb_sum, rto_counts *counts, int threads) {
-    (void)spp_chunk;
-    if (!s || !rgb_sum || y0 < 0 || y1 > s->height || y0 > y1 || sample_count < 0) return 1;
+/* render() per pixel, cpu/main.cpp:45-55, over the pixels [x0, x1) x [y0, y1) of the loop of
+ * :99-106 (rgb_sum is the FULL image buffer; only the window is written).
+ * rto_render below is the whole-rows form; its spp_chunk is accepted for interface symmetry with
+ * rt_opts and has no effect on the result (the sum is exact). */
+int rto_render_rect(const rto_scene *s, uint64_t seed, int x0, int x1, int y0, int y1, int sample_first,
+                    int sample_count, float *rgb_sum, rto_counts *counts, int threads) {
+    if (!s || !rgb_sum || y0 < 0 || y1 > s->height || y0 > y1 || x0 < 0 || x1 > s->width || x0 > x1 ||
+        sample_count < 0)
+        return 1;
     rto_counts total;
     memset(&total, 0, sizeof total);
 #ifdef _OPENMP
@@ -615,7 +618,7 @@ int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_fir
         memset(&local, 0, sizeof local);
 #pragma omp for schedule(dynamic, 1)
         for (int y = y0; y < y1; ++y) {
-            for (int x = 0; x < s->width; ++x) {
+            for (int x = x0; x < x1; ++x) {
                 uint64_t tot[3] = {0, 0, 0};
                 for (int k = 0; k < sample_count; ++k) {
                     float rgb[3];
@@ -633,6 +636,59 @@ int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_fir
     }
     if (counts) *counts = total;
     return 0;
+}
+
+/* whole rows [y0, y1): the pixel loop of cpu/main.cpp:99-106 restricted to a band */
+int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_first,
+               int sample_count, int spp_chunk, float *rgb_sum, rto_counts *counts, int threads) {
+    (void)spp_chunk;
+    if (!s) return 1;
+    return rto_render_rect(s, seed, 0, s->width, y0, y1, sample_first, sample_count, rgb_sum, counts, threads);
+}
+
+/* Timing leg of bench.py's CPU baseline: this restatement on the rows y in [y0, y1) with
+ * ((y - y0) % period) < band (every period-th band of `band` rows), one parallel loop over
+ * (row, 64-pixel span).  Returns seconds; *checksum keeps the work alive. */
+double rto_time_sample(const rto_scene *s, uint64_t seed, int y0, int y1, int period, int band, int spp,
+                       int threads, double *checksum, long long *pixels) {
+    if (!s || period <= 0 || band <= 0 || y0 < 0 || y1 > s->height) return -1.0;
+    int nrows = 0;
+    for (int y = y0; y < y1; ++y)
+        if ((y - y0) % period < band) nrows++;
+    const int spans = (s->width + 63) / 64;
+    const long long jobs = (long long)nrows * spans;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+    double t0 = omp_get_wtime();
+#else
+    threads = 1;
+    clock_t c0 = clock();
+#endif
+    double acc = 0.0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : acc)
+    for (long long j = 0; j < jobs; ++j) {
+        const int r = (int)(j / spans);                 /* r-th sampled row */
+        const int y = y0 + (r / band) * period + r % band;
+        const int xa = (int)(j % spans) * 64, xb = xa + 64 < s->width ? xa + 64 : s->width;
+        for (int x = xa; x < xb; ++x) {
+            uint64_t tot[3] = {0, 0, 0};
+            for (int k = 0; k < spp; ++k) {
+                float rgb[3];
+                rto_sample(s, seed, x, y, k, rgb, 0);
+                tot[0] += radiance_to_fixed(rgb[0]);
+                tot[1] += radiance_to_fixed(rgb[1]);
+                tot[2] += radiance_to_fixed(rgb[2]);
+            }
+            acc += (double)fixed_to_sum(tot[0]) + (double)fixed_to_sum(tot[1]) + (double)fixed_to_sum(tot[2]);
+        }
+    }
+    if (checksum) *checksum = acc;
+    if (pixels) *pixels = (long long)nrows * s->width;
+#ifdef _OPENMP
+    return omp_get_wtime() - t0;
+#else
+    return (double)(clock() - c0) / CLOCKS_PER_SEC;
+#endif
 }
 
 /* aabb::hit, gpu/aabb.hpp:15-29 (slab test; t-range in double as the reference has it) */

@@ -88,6 +88,13 @@ int rto_trace_sample(const rto_scene *s, uint64_t seed, int x, int y, int sample
                      float *queries8, int max_queries);
 int rto_render(const rto_scene *s, uint64_t seed, int y0, int y1, int sample_first,
                int sample_count, int spp_chunk, float *rgb_sum, rto_counts *counts, int threads);
+/* the same over the pixel window [x0, x1) x [y0, y1) only (rgb_sum is still the full W*H buffer) */
+int rto_render_rect(const rto_scene *s, uint64_t seed, int x0, int x1, int y0, int y1, int sample_first,
+                    int sample_count, float *rgb_sum, rto_counts *counts, int threads);
+
+/* bench.py's CPU-baseline timing of this restatement on a systematic row sample (seconds) */
+double rto_time_sample(const rto_scene *s, uint64_t seed, int y0, int y1, int period, int band, int spp,
+                       int threads, double *checksum, long long *pixels);
 
 void rto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void rto_sample_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t *out, int n);

@@ -107,6 +107,7 @@ class Stats(C.Structure):
         ("cull_prefix", C.c_int32),
         ("cull_clusters", C.c_int32), ("cull_groups", C.c_int32), ("cull_cluster_size", C.c_int32),
         ("wave_start_spread_us", C.c_double), ("wave_end_spread_us", C.c_double), ("wave_span_us", C.c_double),
+        ("gather_ms", C.c_double), ("devices_used", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):
@@ -129,6 +130,7 @@ _sig("rt_last_error", C.c_char_p)
 _sig("rt_status_string", C.c_char_p, C.c_int)
 _sig("rt_abi_version", C.c_int)
 _sig("rt_device_count", C.c_int)
+_sig("rt_struct_size", C.c_size_t, C.c_int)
 _sig("rt_opts_default", None, C.POINTER(Opts))
 _sig("rt_scene_load_json", _p, C.c_char_p)
 _sig("rt_scene_parse_json", _p, C.c_char_p, C.c_size_t)
@@ -161,6 +163,9 @@ _sig("rt_shard_rows", C.c_int, _p, C.POINTER(Opts))
 _sig("rt_shard_global_row", C.c_int, _p, C.POINTER(Opts), C.c_int)
 _sig("rt_render_hip_device", C.c_int, _p, C.POINTER(Opts), _p, _p, C.POINTER(Stats))
 _sig("rt_render_hip", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
+_sig("rt_render_hip_tiles", C.c_int, _p, C.POINTER(Opts), C.POINTER(C.c_int), C.c_int, _p, C.POINTER(Stats))
+_sig("rt_tiles_shutdown", None)
+_sig("rt_shard_place_rows_device", C.c_int, _p, C.POINTER(Opts), C.c_int, C.c_int, _p, _p, _p)
 _sig("rt_scene_set_russian_roulette", C.c_int, _p, C.c_float)
 _sig("rt_render_hip_count", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
 _sig("rt_render_hip_accumulate", C.c_int, _p, C.POINTER(Opts), _p, _p, C.POINTER(Stats))
@@ -175,14 +180,14 @@ _sig("rt_aabb_hit", C.c_int, _f3, _f3, _f3, _f3, C.c_float, C.c_float)
 _sig("rt_sample_stream", None, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int)
 
 C_SYMBOLS = [
-    "rt_last_error", "rt_status_string", "rt_abi_version", "rt_device_count", "rt_opts_default",
+    "rt_last_error", "rt_status_string", "rt_abi_version", "rt_struct_size", "rt_device_count", "rt_opts_default",
     "rt_scene_load_json", "rt_scene_parse_json", "rt_scene_rtiow", "rt_scene_to_json", "rt_scene_free",
     "rt_scene_new", "rt_scene_set_background", "rt_scene_set_camera", "rt_scene_add_solid_color",
     "rt_scene_add_checker", "rt_scene_add_lambertian", "rt_scene_add_metal", "rt_scene_add_dielectric",
     "rt_scene_add_diffuse_light", "rt_scene_add_sphere", "rt_scene_add_rect", "rt_scene_add_cylinder",
     "rt_scene_override", "rt_scene_get_info", "rt_scene_get_camera", "rt_scene_get_prims",
     "rt_scene_get_materials", "rt_scene_get_textures", "rt_shard_rows", "rt_shard_global_row",
-    "rt_render_hip_device", "rt_render_hip", "rt_render_hip_count", "rt_render_hip_accumulate", "rt_scene_set_russian_roulette",
+    "rt_render_hip_device", "rt_render_hip", "rt_render_hip_tiles", "rt_tiles_shutdown", "rt_shard_place_rows_device", "rt_render_hip_count", "rt_render_hip_accumulate", "rt_scene_set_russian_roulette",
     "rt_acc_to_rgb", "rt_shard_scatter_rows", "rt_write_ppm",
     "rt_quantize_rgb8", "rt_philox4x32_10", "rt_aabb_hit", "rt_sample_stream", "rt_write_png",
     "rt_scene_output_file", "rt_scene_rotate_cylinders", "rt_scene_set_output_file", "rt_scene_dna", "rt_scene_clone",
@@ -394,6 +399,26 @@ class Scene:
         _check(_lib.rt_render_hip(self._h, C.byref(opts), out.ctypes.data_as(C.c_void_p), C.byref(st)), "rt_render_hip")
         return out
 
+    def render_tiles(self, devices=None, opts: Opts | None = None, stats: Stats | None = None, n: int | None = None):
+        """One frame over several GPUs of this node: row tiles interleaved over `devices` (ordinals; None =
+        0..n-1), one ncclGather to devices[0] (rt_render_hip_tiles).  Returns the (H, W, 3) fp32 sums."""
+        opts = opts or Opts()
+        if devices is None:
+            count = int(n if n is not None else 1)
+            arr = None
+        else:
+            count = len(devices)
+            arr = (C.c_int * count)(*[int(d) for d in devices])
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        _check(_lib.rt_render_hip_tiles(self._h, C.byref(opts), arr, count, out.ctypes.data_as(C.c_void_p),
+                                        C.byref(stats) if stats is not None else None), "rt_render_hip_tiles")
+        return out
+
+    def place_rows_device(self, opts: Opts, n_ranks: int, pad_rows: int, gathered_ptr: int, full_ptr: int, stream: int = 0):
+        """Gathered [n_ranks][pad_rows][W][3] device buffer -> full [H][W][3] device buffer (one kernel)."""
+        _check(_lib.rt_shard_place_rows_device(self._h, C.byref(opts), n_ranks, pad_rows, C.c_void_p(gathered_ptr),
+                                               C.c_void_p(full_ptr), C.c_void_p(stream)), "rt_shard_place_rows_device")
+
     def render_device(self, opts: Opts, device_ptr: int, stream: int = 0, stats: Stats | None = None):
         """Render into a device buffer (e.g. a torch tensor's data_ptr()) on a HIP stream."""
         _check(_lib.rt_render_hip_device(self._h, C.byref(opts), C.c_void_p(device_ptr), C.c_void_p(stream),
@@ -502,6 +527,10 @@ def aabb_hit(bmin, bmax, orig, direction, t_min, t_max) -> bool:
 
 def device_count() -> int:
     return _check_id(_lib.rt_device_count(), "rt_device_count")
+
+
+def struct_size(which: int) -> int:
+    return int(_lib.rt_struct_size(which))
 
 
 def abi_version() -> int:

@@ -37,6 +37,19 @@ extern "C" {
 
 int rt_abi_version(void) { return RTMI_ABI_VERSION; }
 
+size_t rt_struct_size(int which) {
+    switch (which) {
+    case 0: return sizeof(rt_opts);
+    case 1: return sizeof(rt_stats);
+    case 2: return sizeof(rt_prim);
+    case 3: return sizeof(rt_material);
+    case 4: return sizeof(rt_texture);
+    case 5: return sizeof(rt_camera);
+    case 6: return sizeof(rt_scene_info);
+    default: return 0;
+    }
+}
+
 const char *rt_last_error(void) { return get_error(); }
 
 const char *rt_status_string(int status) {

@@ -6,6 +6,9 @@
 // plus --rtiow [--scene-seed S] (the hard-coded random_scene() of main.cpp:125-172),
 // --seed, -o, --device, --chunk, --dump-json.  Timing goes to stderr like the reference's
 // when() markers (rtweekend.cuh:40).
+// --gpus N renders ONE frame on the first N GPUs of the node: row tiles interleaved over the devices, one
+// RCCL gather (rt_render_hip_tiles); the image is the same bytes as with one GPU.  (The reference's blue.py
+// instead starts one process per GPU per animation frame; rtmi-frames is that shape.)
 // Resumable rendering: --acc-out FILE saves the exact pixel sums, --acc-in FILE continues from them
 // (-spp is then the number of samples to ADD; --spp-begin overrides the first sample index).  Any
 // split of a sample range into runs writes the same main.ppm as one run over the whole range.
@@ -37,7 +40,8 @@ static int usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [-f scene.json | --rtiow] [-w W] [-h H] [-d DEPTH] [-spp N] [-o out.ppm]\n"
             "          [--seed S] [--scene-seed S] [--device N] [--chunk N] [--dump-json file] [--count] [--no-png]\n"
-            "          [--acc-in sums.bin] [--acc-out sums.bin] [--spp-begin FIRST] [--rr SURVIVAL_PROBABILITY]\n",
+            "          [--acc-in sums.bin] [--acc-out sums.bin] [--spp-begin FIRST] [--rr SURVIVAL_PROBABILITY]\n"
+            "          [--gpus N] [--tile-rows R]\n",
             argv0);
     return 2;
 }
@@ -49,7 +53,7 @@ int main(int argc, char **argv) {
     long long spp_begin = -1;
     double rr = -1.0;  // Russian roulette: keep the scene file's setting
     bool rtiow = false, have_file = false, count = false, no_png = false;
-    int w = 0, h = 0, depth = 0, spp = 0, device = 0, chunk = 0;
+    int w = 0, h = 0, depth = 0, spp = 0, device = 0, chunk = 0, gpus = 0, tile_rows = 0;
     unsigned long long seed = 2023;
     unsigned scene_seed = 7;  // srand(7), main.cpp:119
     for (int i = 1; i < argc; ++i) {
@@ -70,6 +74,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--scene-seed")) scene_seed = (unsigned)strtoul(need("--scene-seed"), nullptr, 0);
         else if (!strcmp(argv[i], "--device")) device = atoi(need("--device"));
         else if (!strcmp(argv[i], "--chunk")) chunk = atoi(need("--chunk"));
+        else if (!strcmp(argv[i], "--gpus")) gpus = atoi(need("--gpus"));
+        else if (!strcmp(argv[i], "--tile-rows")) tile_rows = atoi(need("--tile-rows"));
         else if (!strcmp(argv[i], "--dump-json")) dump_json = need("--dump-json");
         else if (!strcmp(argv[i], "--acc-in")) acc_in = need("--acc-in");
         else if (!strcmp(argv[i], "--acc-out")) acc_out = need("--acc-out");
@@ -123,11 +129,16 @@ int main(int argc, char **argv) {
     o.seed = seed;
     o.device = device;
     o.spp_chunk = chunk;
+    if (tile_rows > 0) o.tile_rows = tile_rows;
     rt_stats st;
     std::vector<float> img((size_t)info.width * info.height * 3);
     int total_spp = info.samples_per_pixel;  // divisor of the written image
     int rc;
     const bool progressive = !acc_in.empty() || !acc_out.empty() || spp_begin >= 0;
+    if (progressive && gpus > 0) {
+        fprintf(stderr, "rtmi: --gpus cannot be combined with --acc-in/--acc-out/--spp-begin\n");
+        return 2;
+    }
     if (progressive) {
         if (count) {
             fprintf(stderr, "rtmi: --count cannot be combined with --acc-in/--acc-out/--spp-begin\n");
@@ -178,6 +189,15 @@ int main(int argc, char **argv) {
         }
         if (rc == RT_OK)
             fprintf(stderr, "progressive: samples [%lld, %d) added, image holds %d spp\n", spp_begin, total_spp, total_spp);
+    } else if (gpus > 0) {
+        if (count) {
+            fprintf(stderr, "rtmi: --count is a single-device diagnostic; drop --gpus\n");
+            return 2;
+        }
+        rc = rt_render_hip_tiles(sc, &o, nullptr, gpus, img.data(), &st);
+        if (rc == RT_OK)
+            fprintf(stderr, "tiles: %d device(s), slowest render %.3f ms, gather + placement %.3f ms\n", st.devices_used,
+                    st.kernel_ms, st.gather_ms);
     } else {
         rc = count ? rt_render_hip_count(sc, &o, img.data(), &st) : rt_render_hip(sc, &o, img.data(), &st);
     }

@@ -65,6 +65,9 @@ def oracle_lib():
         lib.rto_render.restype = C.c_int
         lib.rto_render.argtypes = [C.POINTER(_RtoScene), C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.POINTER(_RtoCounts), C.c_int]
+        lib.rto_render_rect.restype = C.c_int
+        lib.rto_render_rect.argtypes = [C.POINTER(_RtoScene), C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p, C.POINTER(_RtoCounts), C.c_int]
         lib.rto_derive_camera.restype = None
         lib.rto_derive_camera.argtypes = [C.POINTER(_RtoCameraParams), C.POINTER(_RtoCamera)]
         lib.rto_philox4x32_10.restype = None
@@ -151,6 +154,17 @@ def oracle_render(scene, seed=2023, rows=None, sample_first=0, sample_count=None
                         C.byref(counts) if want_counts else None, threads)
     assert rc == 0
     return out, (counts.as_dict() if want_counts else None)
+
+
+def oracle_render_rect(scene, seed, x0, x1, y0, y1, sample_first=0, sample_count=None, threads=0):
+    """fp32 sums of the pixel window [x0, x1) x [y0, y1) only, shape (y1 - y0, x1 - x0, 3)."""
+    lib = oracle_lib()
+    osc = scene if isinstance(scene, OracleScene) else OracleScene(scene)
+    n = osc.spp if sample_count is None else sample_count
+    out = np.zeros((osc.height, osc.width, 3), dtype=np.float32)
+    rc = lib.rto_render_rect(C.byref(osc.c), seed, x0, x1, y0, y1, sample_first, n, out.ctypes.data, None, threads)
+    assert rc == 0
+    return out[y0:y1, x0:x1].copy()
 
 
 def oracle_sample(scene, seed, x, y, sample):

@@ -22,7 +22,7 @@ def test_header_symbols_exported(rtmi):
 
 
 def test_abi_version_and_errors(rtmi):
-    assert rtmi.abi_version() == 1
+    assert rtmi.abi_version() == 2
     lib = ctypes.CDLL(rtmi.LIB_PATH)
     lib.rt_status_string.restype = ctypes.c_char_p
     assert lib.rt_status_string(0) == b"ok"
@@ -35,7 +35,12 @@ def test_struct_layouts_match_checker(rtmi):
     assert rtmi.MATERIAL_DTYPE.itemsize == 28
     assert rtmi.TEXTURE_DTYPE.itemsize == 28
     assert ctypes.sizeof(rtmi.Opts) == 40
-    assert ctypes.sizeof(rtmi.Stats) == 8 * 2 + 4 * 2 + 8 * 5 + 8 * 4 + 8 + 32 + 8 + 16 + 32 + 48 + 24
+    # the ctypes mirrors against the structs the library was compiled with
+    assert ctypes.sizeof(rtmi.Opts) == rtmi.struct_size(0)
+    assert ctypes.sizeof(rtmi.Stats) == rtmi.struct_size(1) == 8 * 2 + 4 * 2 + 8 * 5 + 8 * 4 + 8 + 32 + 8 + 16 + 32 + 48 + 24 + 16
+    assert rtmi.PRIM_DTYPE.itemsize == rtmi.struct_size(2) and rtmi.MATERIAL_DTYPE.itemsize == rtmi.struct_size(3)
+    assert rtmi.TEXTURE_DTYPE.itemsize == rtmi.struct_size(4)
+    assert ctypes.sizeof(rtmi._Camera) == rtmi.struct_size(5) and ctypes.sizeof(rtmi._Info) == rtmi.struct_size(6)
 
 
 def test_no_oracle_in_product():
