@@ -462,8 +462,10 @@ def cpu_baseline(rtmi, args):
         rs = rtcheck.RefScene(sc)
         chk, px = C.c_double(), C.c_longlong()
         # sampling error: the same estimator on the three other phases of the systematic sample at 1/8 of the spp
+        cpu0 = time.process_time()
         sec = lib.ref_time_sample(rs.h, args.seed, args.width, args.height, 0, args.height, period, band, spp,
                                   args.depth, cores, C.byref(chk), C.byref(px))
+        busy = (time.process_time() - cpu0) / sec  # CPU seconds per wall second = cores the leg really had
         n_samples = px.value * spp
         rate = n_samples / sec / 1e6
         phase_rates = []
@@ -476,6 +478,7 @@ def cpu_baseline(rtmi, args):
         what = ("cmake-cpu-version render() per pixel (oracle/_ref: the reference's own sources + hooked rand()), "
                 f"OpenMP over (row, 64-pixel span) on {cores} threads")
         legs["ii_reference_all_cores"] = {"Msamples_per_s": round(rate, 4), "threads": cores, "seconds": round(sec, 2),
+                                         "cores_busy": round(busy, 1),
                                          "samples": n_samples,
                                          "sampling_spread": round(spread, 4),
                                          "sampling_note": "max-min over the four phases of the every-4th-band sample, "
