@@ -128,7 +128,9 @@ typedef struct rt_scene rt_scene; /* opaque; gpu-version/parser.hpp:16-32 `struc
  * camera{lookfrom lookat vup vfov aperture} object.data[] material.data[]
  * texture.data[] [output_file].  Extensions: texture type "checker"
  * {even[3], odd[3]} (texture.cuh:33-57 has the class, the parser lacks it),
- * optional top-level "sky_gradient": bool, "defocus_blur": bool and "russian_roulette": number in [0, 1].
+ * optional top-level "sky_gradient": bool, "defocus_blur": bool (both default false: gpu-version renders a
+ * constant background, main.cu:63, and has the lens sample disabled, camera.cuh:33-34) and
+ * "russian_roulette": number in [0, 1].
  * Unknown object/material/texture "type" is a hard error (the reference
  * silently leaves the slot uninitialised). Returns NULL on failure. */
 rt_scene *rt_scene_load_json(const char *path);
@@ -215,16 +217,17 @@ typedef struct rt_opts {
     int32_t tile_first;
     int32_t tile_stride;
     /* samples per work item (one wave renders an 8x8 tile x spp_chunk samples at a time).
-     * Scheduling only: the per-pixel sum is exact (64-bit fixed point, 2^-32), so the
+     * Scheduling only: the per-pixel sum is exact (64-bit fixed point, 2^-24), so the
      * framebuffer does not depend on it.  0 -> 64.                                  */
     int32_t spp_chunk;
     int32_t sample_first; /* render samples [sample_first, sample_first+count) */
     int32_t sample_count; /* 0 -> scene spp                                    */
     uint32_t variant;     /* 0 = default kernel; ablation builds (same results): bit 0 strict
-                             one-lane-per-pixel, bit 1 no LDS prefetch, bit 3 scalar-cache table,
+                             one-lane-per-pixel, bit 1 no LDS prefetch (linear scans), bit 3 scalar-cache table,
                              bit 4 no cluster culling (linear scan of every sphere), bit 5 wave-level
-                             cluster votes; 40 = default algorithm with all tables in global memory
-                             (what variant 0 switches to for scenes too large for LDS) */
+                             cluster votes, bit 6 per-lane cluster lists through the two-level box hierarchy
+                             instead of the range tables (round 1's default); 40 / 104 = variant 0 / 64 with all
+                             tables in global memory (what they switch to for scenes too large for LDS) */
 } rt_opts;
 
 typedef struct rt_stats {
@@ -250,6 +253,7 @@ typedef struct rt_stats {
     double wave_start_spread_us, wave_end_spread_us, wave_span_us; /* first-to-last wave start / exit, first start
                                         to last exit (s_memrealtime) */
     /* rt_render_hip_tiles only: kernel_ms above is the SLOWEST device's render launches */
+    uint64_t lane_cands;  /* culling by range tables: candidate clusters per LANE before the per-cluster box test */
     double gather_ms;     /* root device: end of its own render -> assembled frame (ncclGather + row placement,
                              includes waiting for slower peers) */
     int32_t devices_used;
@@ -299,7 +303,8 @@ int rt_render_hip_count(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_
 /* Progressive / resumable rendering (the reference's only analogue is the running
  * average of the Taichi renderers, taichi-version/4_0_path_tracing.py).  `acc` is the caller's
  * exact pixel sums for this shard, [local_rows][width][3] signed 64-bit fixed point in units of
- * 2^-32 (zero-initialised before the first call).  The call adds the samples
+ * 2^-24 (zero-initialised before the first call; a sample is clamped to +-2^16 and at most 2^23 samples per
+ * pixel are accepted, so the sums never wrap).  The call adds the samples
  * [sample_first, sample_first + sample_count) of `o` to it; integer addition is exact and
  * commutative, so any split of a sample range into calls, processes or devices gives the same
  * sums -- and the same framebuffer -- as one rt_render_hip call over the whole range.
@@ -307,7 +312,7 @@ int rt_render_hip_count(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_
 int rt_render_hip_accumulate(const rt_scene *s, const rt_opts *o, int64_t *acc, float *rgb_sum,
                              rt_stats *stats);
 
-/* fp32 framebuffer values of exact sums: rgb_sum[i] = (float)(acc[i] * 2^-32), the conversion the
+/* fp32 framebuffer values of exact sums: rgb_sum[i] = (float)(acc[i] * 2^-24), the conversion the
  * render path itself applies once per launch. */
 void rt_acc_to_rgb(const int64_t *acc, float *rgb_sum, size_t n_values);
 

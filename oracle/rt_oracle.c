@@ -586,15 +586,16 @@ static void counts_add(rto_counts *a, const rto_counts *b) {
 
 /* Pixel accumulation.  The reference adds sample radiances into a running sum
  * (res += ray_color(...), cpu/main.cpp:47,52: fp64; gpu/main.cu:100: fp32).  Here each
- * fp32 sample is converted to 64-bit fixed point with 32 fractional bits (round to nearest
- * even) and summed in integers: exact, hence independent of the order in which samples
- * finish -- which lets the HIP kernel hand samples of a tile to whichever lane is free.
- * (resolution 2^-32 per sample, closer to the fp64 reference than an fp32 running sum). */
+ * fp32 sample is converted to 64-bit fixed point with 24 fractional bits (round to nearest
+ * even, |sample| clamped to 2^16, NaN -> 0) and summed in integers: exact, hence independent of
+ * the order in which samples finish -- which lets the HIP kernel hand samples of a tile to
+ * whichever lane is free.  (Resolution 2^-25 per sample: below the rounding of the one final
+ * conversion to fp32 for every sum >= 1; 2^23 samples of the largest value cannot wrap the sum.) */
 static uint64_t radiance_to_fixed(float v) {
-    if (!(fabsf(v) <= 1e9f)) v = (v != v) ? 0.0f : copysignf(1e9f, v); /* NaN -> 0, clamp */
-    return (uint64_t)llrint((double)v * 4294967296.0);
+    if (!(fabsf(v) <= 65536.0f)) v = (v != v) ? 0.0f : copysignf(65536.0f, v); /* NaN -> 0, clamp */
+    return (uint64_t)llrint((double)v * 16777216.0);
 }
-static float fixed_to_sum(uint64_t t) { return (float)((double)(int64_t)t * (1.0 / 4294967296.0)); }
+static float fixed_to_sum(uint64_t t) { return (float)((double)(int64_t)t * (1.0 / 16777216.0)); }
 
 /* render() per pixel, cpu/main.cpp:45-55, over the pixels [x0, x1) x [y0, y1) of the loop of
  * :99-106 (rgb_sum is the FULL image buffer; only the window is written).

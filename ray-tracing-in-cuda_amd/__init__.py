@@ -107,7 +107,7 @@ class Stats(C.Structure):
         ("cull_prefix", C.c_int32),
         ("cull_clusters", C.c_int32), ("cull_groups", C.c_int32), ("cull_cluster_size", C.c_int32),
         ("wave_start_spread_us", C.c_double), ("wave_end_spread_us", C.c_double), ("wave_span_us", C.c_double),
-        ("gather_ms", C.c_double), ("devices_used", C.c_int32), ("reserved_", C.c_int32),
+        ("lane_cands", C.c_uint64), ("gather_ms", C.c_double), ("devices_used", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def as_dict(self):
@@ -439,7 +439,7 @@ class Scene:
     def accumulate(self, acc: np.ndarray | None = None, opts: Opts | None = None, stats: Stats | None = None,
                    want_image=True):
         """Progressive rendering: add the samples [opts.sample_first, +sample_count) to the exact pixel sums
-        `acc` (int64 [local_rows, width, 3], 2^-32 units; None = start from zero).  Returns (acc, image)."""
+        `acc` (int64 [local_rows, width, 3], 2^-24 units; None = start from zero).  Returns (acc, image)."""
         opts = opts or Opts()
         rows = self.shard_rows(opts)
         if acc is None:
@@ -461,7 +461,7 @@ class Scene:
 
 
 def acc_to_rgb(acc: np.ndarray) -> np.ndarray:
-    """fp32 framebuffer values of exact int64 pixel sums (2^-32 units)."""
+    """fp32 framebuffer values of exact int64 pixel sums (2^-24 units)."""
     acc = np.ascontiguousarray(acc, dtype=np.int64)
     out = np.empty(acc.shape, dtype=np.float32)
     _lib.rt_acc_to_rgb(acc.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), acc.size)

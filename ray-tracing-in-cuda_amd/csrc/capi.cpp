@@ -339,7 +339,7 @@ rt_scene *rt_scene_dna(const rt_scene *base, double angle) {
     } else {  // gpu-version/basic_scene.json
         sc.width = 1600, sc.height = 900, sc.spp = 100, sc.max_depth = 50;
         sc.background[0] = 0.0005f, sc.background[1] = 0.0007f, sc.background[2] = 0.00099f;
-        sc.flags = RT_FLAG_DEFOCUS_BLUR;
+        sc.flags = 0;  // constant background, no lens sampling: what gpu-version renders from that file
         sc.cam = CameraParams();
         sc.cam.lookfrom[0] = 0, sc.cam.lookfrom[1] = 0, sc.cam.lookfrom[2] = -20;
         sc.cam.vfov = 23, sc.cam.aperture = 0.1;
@@ -470,7 +470,7 @@ static inline int quantize(float sum, int spp, int gamma) {
 void rt_acc_to_rgb(const int64_t *acc, float *rgb_sum, size_t n_values) {
     if (!acc || !rgb_sum) return;
     // same expression as the device's finalize step (render_kernel.hip): exact in double, one rounding to float
-    for (size_t i = 0; i < n_values; ++i) rgb_sum[i] = (float)((double)acc[i] * (1.0 / 4294967296.0));
+    for (size_t i = 0; i < n_values; ++i) rgb_sum[i] = (float)((double)acc[i] * (1.0 / 16777216.0));
 }
 
 int rt_quantize_rgb8(const float *rgb_sum, int width, int height, int spp, int gamma, uint8_t *out) {

@@ -26,7 +26,15 @@
 #define RT_GROUP 4
 #endif
 
-// most short chunks at the end of a launch's work queue
+// slabs per axis of a window box in the range tables (candidate clusters of a ray segment): R[i0 * RT_SLABS + i1]
+#ifndef RT_SLABS
+#define RT_SLABS 16
+#endif
+
+// Pixel sums: signed 64-bit fixed point with RT_FIX_BITS fractional bits (include/rtmi.h, rt_render_hip_accumulate)
+#define RT_FIX_BITS 24
+#define RT_FIX_CLAMP 65536.0f
+#define RT_MAX_SAMPLES_PER_PIXEL (1 << 23)
 
 namespace rtmi {
 
@@ -73,8 +81,11 @@ struct RenderParams {
     int32_t ngr, off_gbox;   // outer boxes over RT_GROUP consecutive clusters
     int32_t nwin, off_wbox;  // window boxes over 64 consecutive clusters (64 / RT_GROUP outer boxes)
     int32_t off_cbox;        // 2 float4 per cylinder: world-space bounding box of the open tube
+    // range tables: per window {box min.xyz}, {1 / slab width .xyz}, then per enabled axis RT_SLABS^2 64-bit masks
+    int32_t off_rtab, rt_stride, rt_axes;  // float4 offset, float4 records per window, enabled axes (bit a)
+    int32_t hot_vec4_tables; // float4 count of the hot part including the range tables (what the range-table kernel stages)
     float cull_extent1;      // 1 + max |coordinate| of the clustered spheres (per-lane box margin, see packer)
-    int32_t hot_vec4;        // float4 count of the hot part (LDS bytes / 16)
+    int32_t hot_vec4;        // float4 count of the hot part without the range tables (LDS bytes / 16 of the other variants)
     int32_t off_rect_hot;    // float4 offsets inside the image
     int32_t off_cyl_hot;
     int32_t off_sph_cold;
@@ -103,6 +114,7 @@ struct DevCounters {
     unsigned long long cycles[6];  // shader-clock time per main-loop section, summed over waves
     unsigned long long group_maxpop, query_maxpop;  // culling: max over lanes of needed clusters, per visited group / per wave-query
     unsigned long long wave_queries;             // closest-hit queries executed per wave (loop iterations)
+    unsigned long long lane_cands;               // range tables: candidate clusters per lane (before the box test)
 };
 
 }  // namespace rtmi

@@ -29,6 +29,7 @@ void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStr
 void launch_item_params(unsigned int *queue, const ItemParams &ip, hipStream_t stream);
 int set_max_dynamic_lds(size_t bytes);
 bool variant_exists(unsigned variant);
+int variant_cull_mode(unsigned variant);
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -148,10 +149,19 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         std::sort(ext, ext + 3);
         if (ext[1] > 0.0f && ext[0] < 0.1f * ext[1]) csize = 16;  // a sheet, not a volume
     }
-    for (int i : rest) slots.push_back(i);
-    while ((slots.size() - np_slots) % csize) slots.push_back(-1);
-    const int n_clusters = ((int)slots.size() - np_slots) / csize;
-    while (slots.size() % 8) slots.push_back(-1);  // the flat scan walks 8 slots per iteration
+    // Cluster q occupies the slots [np + q (csize + 1), + csize) followed by ONE never-hit slot: with a stride of
+    // csize + 1 records, record h of clusters q and q' lies (q - q') records apart modulo 16, so the lanes of a wave
+    // that walk different clusters read different LDS banks with the same instruction (a ds_read_b128 serves 16
+    // lanes per cycle, one 16-byte record per 4 banks; with stride 16 every cluster's record h shared one bank group:
+    // 19.5 % of the LDS cycles were conflicts).  All-padding clusters end the table (read-ahead of the flat scans).
+    const int n_clusters = ((int)rest.size() + csize - 1) / csize;
+    const int cstride = csize + 1;
+    for (int q = 0; q < n_clusters + 3; ++q)  // + 3 all-padding clusters: the flat scan reads 16 records a step and one ahead
+        for (int h = 0; h < cstride; ++h) {
+            const size_t j = (size_t)q * csize + h;
+            slots.push_back((q < n_clusters && h < csize && j < rest.size()) ? rest[j] : -1);
+        }
+    while (slots.size() % 4) slots.push_back(-1);
     const int ns_slots = (int)slots.size();
 
     RenderParams &L = c.layout;
@@ -167,8 +177,6 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     off += 2 * n_clusters;
     const int n_groups = (n_clusters + RT_GROUP - 1) / RT_GROUP;  // RT_GROUP consecutive clusters share an outer box
     L.ngr = n_groups;
-    L.off_gbox = off;
-    off += 2 * n_groups;
     const int groups_per_window = 64 / RT_GROUP;  // one 64-bit cluster mask per window in the kernel
     const int n_windows = (n_groups + groups_per_window - 1) / groups_per_window;
     L.nwin = n_windows;
@@ -182,7 +190,32 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     off += 2 * L.nc;
     L.off_cam = off;  // camera::camera's derived vectors (camera.h:9-31): read once per new sample
     off += 6;
-    L.hot_vec4 = off;
+    // Range tables (candidate clusters of a ray segment without testing every box): per window of 64 clusters and
+    // per enabled axis, R[i0 * 16 + i1] = the clusters whose box overlaps the slabs i0..i1 of the window box cut
+    // into RT_SLABS slabs along that axis (64-bit mask).  The clusters a ray can reach are a subset of
+    // R_x[..] & R_y[..] & R_z[..] taken at the slab ranges of the segment's bounding box.  An axis along which the
+    // clustered spheres do not spread (a sheet: RTIOW's y) carries no information and is left out (2 KB of LDS).
+    int axes = 0;
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i : rest) {
+            const float r = std::fabs(s.prims[i].f[3]);
+            for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], s.prims[i].f[a] - r), hi[a] = std::max(hi[a], s.prims[i].f[a] + r);
+        }
+        float ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        const float big = std::max(ext[0], std::max(ext[1], ext[2]));
+        for (int a = 0; a < 3; ++a)
+            if (!rest.empty() && ext[a] > 0.05f * big) axes |= 1 << a;
+    }
+    int n_axes = (axes & 1) + ((axes >> 1) & 1) + ((axes >> 2) & 1);
+    L.off_gbox = off;  // outer boxes: the box-hierarchy variants read them
+    off += 2 * n_groups;
+    L.hot_vec4 = off;  // what every variant but the range-table kernel stages into LDS
+    L.rt_axes = axes;
+    L.rt_stride = 2 + n_axes * (RT_SLABS * RT_SLABS / 2);  // float4 records per window: {min, 1/width} + masks (2 per record)
+    L.off_rtab = off;
+    off += n_windows * L.rt_stride;
+    L.hot_vec4_tables = off;  // ... and the range-table kernel: the same plus the tables
     L.off_sph_cold = off;
     off += ns_slots;
     L.off_rect_cold = off;
@@ -263,7 +296,7 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     for (int q = 0; q < n_clusters; ++q) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = 0; k < csize; ++k) {
-            const int pi = slots[np_slots + csize * q + k];
+            const int pi = slots[np_slots + cstride * q + k];
             if (pi < 0) continue;
             const rt_prim &p = s.prims[pi];
             const float r = std::fabs(p.f[3]);
@@ -289,6 +322,45 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         for (int g = w * groups_per_window; g < std::min(n_groups, (w + 1) * groups_per_window); ++g) {
             const float *b = rec4(L.off_gbox + 2 * g);
             for (int a = 0; a < 3; ++a) wb[a] = std::min(wb[a], b[a]), wb[4 + a] = std::max(wb[4 + a], b[4 + a]);
+        }
+    }
+    // range tables of every window (layout: see L.off_rtab above)
+    for (int w = 0; w < n_windows; ++w) {
+        const float *wb = rec4(L.off_wbox + 2 * w);
+        float *hd = rec4(L.off_rtab + w * L.rt_stride);
+        uint64_t *masks = reinterpret_cast<uint64_t *>(hd + 8);
+        const int q0 = w * 64, q1 = std::min(n_clusters, q0 + 64);
+        int ai = 0;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = wb[a], hi = wb[4 + a];
+            const float width = (hi - lo) / (float)RT_SLABS;
+            hd[a] = lo;
+            hd[4 + a] = width > 0.0f ? 1.0f / width : 0.0f;  // a window that is flat on this axis: every point -> slab 0
+            if (!((axes >> a) & 1)) continue;
+            uint64_t slab[RT_SLABS];
+            // the kernel finds a point's slab as floor((x - lo) * (1 / width)) in fp32: grow every slab by a tolerance
+            // far above that rounding so that a cluster touching a slab boundary is listed on both sides
+            const float tol = 1e-3f * width + 1e-5f * (std::fabs(lo) + std::fabs(hi));
+            for (int i = 0; i < RT_SLABS; ++i) {
+                const float a0 = lo + width * (float)i - tol, a1 = lo + width * (float)(i + 1) + tol;
+                uint64_t m = 0;
+                for (int q = q0; q < q1; ++q) {
+                    const float *b = rec4(L.off_box + 2 * q);
+                    // the first and last slab also stand for everything outside the window box on their side
+                    const bool over = (i == 0 || b[4 + a] >= a0) && (i == RT_SLABS - 1 || b[a] <= a1);
+                    if (over || !(width > 0.0f)) m |= 1ull << (q - q0);
+                }
+                slab[i] = m;
+            }
+            uint64_t *R = masks + (size_t)ai * RT_SLABS * RT_SLABS;
+            for (int i0 = 0; i0 < RT_SLABS; ++i0) {
+                uint64_t m = 0;
+                for (int i1 = 0; i1 < RT_SLABS; ++i1) {
+                    if (i1 >= i0) m |= slab[i1];
+                    R[i0 * RT_SLABS + i1] = i1 >= i0 ? m : 0;
+                }
+            }
+            ++ai;
         }
     }
     for (int k = 0; k < L.nr; ++k) {
@@ -497,6 +569,13 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         set_error("sample_first must be >= 0");
         return RT_ERR_ARG;
     }
+    // a sample contributes at most 2^16 (radiance_to_fixed clamps) in units of 2^-24: 2^23 samples keep the 64-bit
+    // pixel sums exact (the reference's float sum saturates gracefully instead; a silent wrap here would not)
+    if ((long long)sample_first + sample_count > RT_MAX_SAMPLES_PER_PIXEL) {
+        set_error("samples [%d, %lld) exceed %d samples per pixel, the range over which the fixed-point pixel sums are exact",
+                  sample_first, (long long)sample_first + sample_count, RT_MAX_SAMPLES_PER_PIXEL);
+        return RT_ERR_LIMIT;
+    }
 
     unsigned variant = o ? o->variant : 0;
     if (!variant_exists(variant)) {
@@ -589,10 +668,14 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // ms); larger scenes run the same algorithm over global memory (variant 40: 1000 spheres 6.4 vs 6.9 ms,
     // 4000 spheres 20 vs 66 ms), which has no size limit.
     const size_t acc_lds = 4 * 192 * sizeof(unsigned long long);  // one 64-pixel rgb accumulator per wave
-    const size_t hot_bytes = (size_t)P.hot_vec4 * 16;
+    // (only the range-table kernels read the tables at the end of the hot part)
+    auto hot_bytes_of = [&](unsigned v) { return (size_t)(variant_cull_mode(v) == 3 ? P.hot_vec4_tables : P.hot_vec4) * 16; };
+    size_t hot_bytes = hot_bytes_of(variant);
     static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
                                                                              : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;
     if (variant == 0 && hot_bytes > global_threshold) variant = 40;
+    if (variant == 64 && hot_bytes > global_threshold) variant = 104;
+    hot_bytes = hot_bytes_of(variant);
     const size_t lds_bytes = ((variant & 8u) ? 0 : hot_bytes) + acc_lds;
     if (lds_bytes > 160 * 1024) {
         set_error("kernel variant %u keeps the scene tables in LDS and this scene needs %zu bytes per workgroup "
@@ -715,6 +798,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->groups_visited = h.groups_visited;
             stats->lane_clusters = h.lane_clusters;
             stats->lane_groups = h.lane_groups;
+            stats->lane_cands = h.lane_cands;
             stats->group_maxpop = h.group_maxpop;
             stats->query_maxpop = h.query_maxpop;
             for (int i = 0; i < 6; ++i) stats->cycles[i] = h.cycles[i];

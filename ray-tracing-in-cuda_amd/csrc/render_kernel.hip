@@ -22,7 +22,7 @@
 //     (variant bit 0 restores strict ownership: a lane only takes samples of its own
 //     pixel.  Results are identical; it is kept to measure what the pool buys.)
 //   * that hand-off is legal because the per-pixel sum is exact: each fp32 sample is
-//     added as 64-bit fixed point (2^-32), in LDS per tile, then one 64-bit global
+//     added as 64-bit fixed point (2^-24), in LDS per tile, then one 64-bit global
 //     atomic per pixel and channel; a second kernel converts to the fp32 framebuffer
 //     with fully coalesced stores.
 //   * the primitive tables the inner loop reads ("hot" part of the scene image,
@@ -49,6 +49,10 @@
 // minimum resident waves per SIMD the register allocator must leave room for (8 <=> 64 VGPRs)
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 7
+#endif
+// the flat-scan ablation kernels (CULL == 0) keep two register sets of sphere records in flight
+#ifndef RT_WAVES_LINEAR
+#define RT_WAVES_LINEAR RT_WAVES_PER_SIMD
 #endif
 
 namespace rtmi {
@@ -98,18 +102,20 @@ __device__ __forceinline__ int list_index_of(const RenderParams &P, const float4
     return __float_as_int(image[P.off_cyl_cold + 4 * (id - P.ns - P.nr) + 3].y);
 }
 
-// radiance sample -> 64-bit fixed point with 32 fractional bits, round to nearest even;
-// NaN -> 0, magnitude clamped to 1e9 (a pixel sum is exact while it stays below 2^31)
+// radiance sample -> 64-bit fixed point with RT_FIX_BITS (24) fractional bits, round to nearest even;
+// NaN -> 0, magnitude clamped to RT_FIX_CLAMP (2^16).  |sample| <= 2^16 and at most 2^23 samples per pixel
+// (checked by the host) keep every pixel sum below 2^39 < 2^63 / 2^24: the integer sums never wrap.
 __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
-    if (!(fabsf(v) <= 1e9f)) v = (v != v) ? 0.0f : copysignf(1e9f, v);
-    // llrint((double)v * 2^32) without fp64: |v| = hi + frac with hi = trunc(|v|) (v_cvt_u32_f32; the
-    // subtraction of the integer part is exact), frac * 2^32 < 2^32 is exact, and rounding it to nearest
-    // even rounds the whole value to nearest even because hi * 2^32 is an even integer.
+    if (!(fabsf(v) <= RT_FIX_CLAMP)) v = (v != v) ? 0.0f : copysignf(RT_FIX_CLAMP, v);
+    // llrint((double)v * 2^24) without fp64: |v| = hi + frac with hi = trunc(|v|) (v_cvt_u32_f32; the
+    // subtraction of the integer part is exact), frac * 2^24 < 2^24 is exact in fp32 arithmetic before the
+    // rounding, and rounding it to nearest even rounds the whole value to nearest even because hi * 2^24 is
+    // an even integer.
     const float a = fabsf(v);
     const uint32_t hi = (uint32_t)a;
     const float frac = a - (float)hi;
-    const uint32_t lo = (uint32_t)rintf(frac * 4294967296.0f);
-    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    const uint32_t lo = (uint32_t)rintf(frac * 16777216.0f);
+    const unsigned long long m = ((unsigned long long)hi << RT_FIX_BITS) + lo;
     return v < 0.0f ? 0ull - m : m;
 }
 
@@ -126,18 +132,24 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 // CULL:     after the always-tested big spheres, clusters of 8 spheres are visited only if some
 //           lane's ray passes the cluster's (inflated) bounding box: slab test of aabb.hpp:15-29
 //           + __any.  Conservative, so results are unchanged; fewer tests are executed.
-// CSIZE:    spheres per cluster (8 or 16: the packer picks per scene, RenderParams::cluster)
-//           2 (default): every lane collects the clusters ITS ray reaches in a bit mask and then walks its
-//           own list (per-lane LDS addresses), so a wave spends max-over-lanes instead of union-over-lanes
-//           cluster visits; 1: the whole wave visits every cluster some lane voted for; 0: no culling
+//           3 (default): every lane looks the CANDIDATE clusters of its ray segment up in the range tables (the
+//           segment's bounding box against precomputed per-axis cluster masks: three LDS reads instead of a
+//           box loop), keeps the candidates whose box its ray really reaches (the slab test above, per lane)
+//           and then walks its own list of clusters (per-lane LDS addresses), so a wave spends max-over-lanes
+//           instead of union-over-lanes cluster visits; 2: the same per-lane lists found through a two-level
+//           box hierarchy that every lane tests in full (round 1's default); 1: the whole wave visits every
+//           cluster some lane voted for; 0: no culling
+// CSIZE:    spheres per cluster (8 or 16: the packer picks per scene, RenderParams::cluster); a cluster occupies
+//           CSIZE + 1 slots (the last one never hit), which keeps the per-lane reads of different clusters on
+//           different LDS banks
 template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL, int CSIZE>
-__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
+__global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SIMD)) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
                                                      unsigned int *__restrict__ queue,
                                                      DevCounters *__restrict__ counters) {
     extern __shared__ float4 lds[];
     // stage the hot tables (hittable_list contents) into LDS
-    const int staged = SCALAR ? 0 : P.hot_vec4;
+    const int staged = SCALAR ? 0 : (CULL == 3 ? P.hot_vec4_tables : P.hot_vec4);
     for (int i = threadIdx.x; i < staged; i += 256) lds[i] = image[i];
     // per-wave tile accumulator of the current work item: 64 pixels x rgb, 64-bit fixed point
     unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + staged);
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
     uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0;
-    uint32_t c_cand = 0, c_cand_wave = 0, c_clusters = 0, c_groups = 0, c_wave_queries = 0, c_lane_clusters = 0, c_lane_groups = 0, c_group_maxpop = 0, c_query_maxpop = 0;
+    uint32_t c_cand = 0, c_cand_wave = 0, c_clusters = 0, c_groups = 0, c_wave_queries = 0, c_lane_clusters = 0, c_lane_groups = 0, c_lane_cands = 0, c_group_maxpop = 0, c_query_maxpop = 0;
     // COUNT: shader-clock time of the main loop's sections, per wave (refill, prefix spheres, culled spheres +
     // rects + cylinders, shading, pixel accumulation, loop control)
     unsigned long long cyc[6] = {0, 0, 0, 0, 0, 0}, tmark = 0, t_qe = 0;
@@ -417,37 +429,54 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
         if (__builtin_expect(cand, 0)) resolve(IDX, hb, disc);                                 \
     }
-            if (CULL) {
-                // the always-tested prefix (big spheres), four records at a time
-                for (int i = 0; i < P.np; i += 4) {
-                    const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
-                    RT_SPHERE_TEST(s0, i)
-                    RT_SPHERE_TEST(s1, i + 1)
-                    RT_SPHERE_TEST(s2, i + 2)
-                    RT_SPHERE_TEST(s3, i + 3)
-                }
-            } else if (PREFETCH) {
-                // flat scan of every slot: two register sets of four records, fetched one half-iteration
-                // ahead of their use; the table is padded to a multiple of 8 with never-hit records
-                // (r*r = -inf) plus 4 more, so the fetches never leave the table
-                float4 a0 = sph[0], a1 = sph[1], a2 = sph[2], a3 = sph[3];
-                for (int i = 0; i < P.ns_pad; i += 8) {
-                    const float4 b0 = sph[i + 4], b1 = sph[i + 5], b2 = sph[i + 6], b3 = sph[i + 7];
-                    RT_SPHERE_TEST(a0, i)
-                    RT_SPHERE_TEST(a1, i + 1)
-                    RT_SPHERE_TEST(a2, i + 2)
-                    RT_SPHERE_TEST(a3, i + 3)
-                    a0 = sph[i + 8], a1 = sph[i + 9], a2 = sph[i + 10], a3 = sph[i + 11];
-                    RT_SPHERE_TEST(b0, i + 4)
-                    RT_SPHERE_TEST(b1, i + 5)
-                    RT_SPHERE_TEST(b2, i + 6)
-                    RT_SPHERE_TEST(b3, i + 7)
-                }
-            } else {
+            // the always-tested prefix (big spheres), four records at a time
+            for (int i = 0; i < P.np; i += 4) {
+                const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
+                RT_SPHERE_TEST(s0, i)
+                RT_SPHERE_TEST(s1, i + 1)
+                RT_SPHERE_TEST(s2, i + 2)
+                RT_SPHERE_TEST(s3, i + 3)
+            }
+            if (!CULL) {
+                // flat scan (the reference's hittable_list loop) of every cluster's CSIZE records (clusters are
+                // CSIZE + 1 slots apart, see the packer)
+                if (PREFETCH) {
+                    // 16 records per iteration (one 16-cluster or two 8-clusters, the never-hit slot between them
+                    // skipped), in two register sets of four fetched half a step ahead of their use; the table ends
+                    // with all-padding clusters, so the last read-ahead stays inside it
+                    constexpr int kStep = CSIZE == 8 ? 18 : 17;
+#define RT_OFF(k) ((k) + ((CSIZE == 8 && (k) >= 8) ? 1 : 0))
+                    const int iters = (P.ncl * CSIZE + 15) / 16;
+                    int base = P.np;
+                    float4 a0 = sph[base], a1 = sph[base + 1], a2 = sph[base + 2], a3 = sph[base + 3];
+                    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                        for (int k = 0; k < 16; k += 8) {
+                            const float4 b0 = sph[base + RT_OFF(k + 4)], b1 = sph[base + RT_OFF(k + 5)],
+                                         b2 = sph[base + RT_OFF(k + 6)], b3 = sph[base + RT_OFF(k + 7)];
+                            RT_SPHERE_TEST(a0, base + RT_OFF(k))
+                            RT_SPHERE_TEST(a1, base + RT_OFF(k + 1))
+                            RT_SPHERE_TEST(a2, base + RT_OFF(k + 2))
+                            RT_SPHERE_TEST(a3, base + RT_OFF(k + 3))
+                            const int nxt = k + 8 < 16 ? RT_OFF(k + 8) : kStep;
+                            a0 = sph[base + nxt], a1 = sph[base + nxt + 1], a2 = sph[base + nxt + 2], a3 = sph[base + nxt + 3];
+                            RT_SPHERE_TEST(b0, base + RT_OFF(k + 4))
+                            RT_SPHERE_TEST(b1, base + RT_OFF(k + 5))
+                            RT_SPHERE_TEST(b2, base + RT_OFF(k + 6))
+                            RT_SPHERE_TEST(b3, base + RT_OFF(k + 7))
+                        }
+                        base += kStep;
+                    }
+#undef RT_OFF
+                } else {
+                    for (int q = 0; q < P.ncl; ++q) {
+                        const int base = P.np + (CSIZE + 1) * q;
 #pragma unroll 4
-                for (int i = 0; i < P.ns_pad; ++i) {
-                    const float4 s = sph[i];
-                    RT_SPHERE_TEST(s, i)
+                        for (int h = 0; h < CSIZE; ++h) {
+                            const float4 s = sph[base + h];
+                            RT_SPHERE_TEST(s, base + h)
+                        }
+                    }
                 }
             }
             tick(1);
@@ -485,7 +514,95 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                 const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), blim), fmaxf(lz, uz));
                 return !(tn > tf);
             };
-            if (CULL == 2) {
+            if (CULL == 3) {
+                // windows of 64 clusters: one mask bit per cluster
+                for (int w0 = 0; w0 < P.nwin; ++w0) {
+                    // clip the ray to the window box (the union of its cluster boxes; same margin as every box test)
+                    const float4 *wb = hot + P.off_wbox + 2 * w0;
+                    const float4 wmn = wb[0], wmx = wb[1];
+                    blim = best_t * 1.0001f;  // what the prefix and the previous windows found
+                    const float lx = fmaf(wmn.x, idx, nxm), ux = fmaf(wmx.x, idx, nxp);
+                    const float ly = fmaf(wmn.y, idy, nym), uy = fmaf(wmx.y, idy, nyp);
+                    const float lz = fmaf(wmn.z, idz, nzm), uz = fmaf(wmx.z, idz, nzp);
+                    const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
+                    const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), blim), fmaxf(lz, uz));
+                    const bool wlive = !(tn > tf);
+                    if (__builtin_amdgcn_ballot_w64(wlive) == 0ull) continue;
+                    if (COUNT) c_lane_groups += wlive ? 1u : 0u;
+                    // phase 1: candidate clusters of the clipped segment [tn, tf]: the slab ranges of its bounding box
+                    // (grown by the margin) select one precomputed mask per axis -- R_a[i0][i1] = clusters whose box
+                    // overlaps the slabs i0..i1 of the window along axis a; a cluster the ray can reach overlaps the
+                    // segment's box on every axis, so it is in the intersection of the three masks
+                    unsigned long long cand = 0ull;
+                    if (wlive) {
+                        const float4 *hd = hot + P.off_rtab + w0 * P.rt_stride;
+                        const float4 gmn = hd[0], giw = hd[1];
+                        const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(hd + 2);
+                        cand = ~0ull;
+                        const float top = (float)(RT_SLABS - 1);
+                        if (P.rt_axes & 1) {
+                            const float a = fmaf(tn, dx, ox), b = fmaf(tf, dx, ox);
+                            const int i0 = (int)__builtin_amdgcn_fmed3f(((fminf(a, b) - marg) - gmn.x) * giw.x, 0.0f, top);
+                            const int i1 = (int)__builtin_amdgcn_fmed3f(((fmaxf(a, b) + marg) - gmn.x) * giw.x, 0.0f, top);
+                            cand &= tab[i0 * RT_SLABS + i1];
+                            tab += RT_SLABS * RT_SLABS;
+                        }
+                        if (P.rt_axes & 2) {
+                            const float a = fmaf(tn, dy, oy), b = fmaf(tf, dy, oy);
+                            const int i0 = (int)__builtin_amdgcn_fmed3f(((fminf(a, b) - marg) - gmn.y) * giw.y, 0.0f, top);
+                            const int i1 = (int)__builtin_amdgcn_fmed3f(((fmaxf(a, b) + marg) - gmn.y) * giw.y, 0.0f, top);
+                            cand &= tab[i0 * RT_SLABS + i1];
+                            tab += RT_SLABS * RT_SLABS;
+                        }
+                        if (P.rt_axes & 4) {
+                            const float a = fmaf(tn, dz, oz), b = fmaf(tf, dz, oz);
+                            const int i0 = (int)__builtin_amdgcn_fmed3f(((fminf(a, b) - marg) - gmn.z) * giw.z, 0.0f, top);
+                            const int i1 = (int)__builtin_amdgcn_fmed3f(((fmaxf(a, b) + marg) - gmn.z) * giw.z, 0.0f, top);
+                            cand &= tab[i0 * RT_SLABS + i1];
+                        }
+                        const int left = P.ncl - w0 * 64;  // the last window may hold fewer than 64 clusters
+                        if (left < 64) cand &= (1ull << left) - 1ull;
+                        if (COUNT) c_lane_cands += (uint32_t)__popcll(cand);
+                    }
+                    // phase 2: keep the candidates whose own box the ray reaches (per-lane box reads)
+                    unsigned long long mine = 0ull;
+                    while (__builtin_amdgcn_ballot_w64(cand != 0ull) != 0ull) {
+                        if (cand != 0ull) {
+                            const unsigned long long low = cand & (0ull - cand);
+                            const int q = (int)__builtin_ctzll(cand);
+                            cand ^= low;
+                            const float4 *b = box + 2 * (w0 * 64 + q);
+                            if (slab_live(b[0], b[1])) mine |= low;
+                        }
+                        if (COUNT) c_groups++;
+                    }
+                    if (COUNT) {
+                        c_lane_clusters += (uint32_t)__popcll(mine);
+                        uint32_t m = (uint32_t)__popcll(mine);
+                        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+                        if (lane == 0) c_query_maxpop += m;
+                    }
+                    // phase 3: every lane walks its own clusters; lanes that are done wait masked off
+                    while (__builtin_amdgcn_ballot_w64(mine != 0ull) != 0ull) {
+                        if (mine != 0ull) {
+                            const int q = (int)__builtin_ctzll(mine);
+                            mine &= mine - 1ull;
+                            const int base = P.np + (CSIZE + 1) * (w0 * 64 + q);
+                            const float4 *cs = sph + base;
+#pragma unroll
+                            for (int h = 0; h < CSIZE; h += 4) {
+                                const float4 r0 = cs[h], r1 = cs[h + 1], r2 = cs[h + 2], r3 = cs[h + 3];
+                                RT_SPHERE_TEST(r0, base + h)
+                                RT_SPHERE_TEST(r1, base + h + 1)
+                                RT_SPHERE_TEST(r2, base + h + 2)
+                                RT_SPHERE_TEST(r3, base + h + 3)
+                            }
+                        }
+                        if (COUNT) c_clusters++;
+                    }
+                }
+                blim = best_t * 1.0001f;
+            } else if (CULL == 2) {
                 // windows of 64 clusters (16 outer boxes): one mask bit per cluster
                 for (int g0 = 0; g0 < P.ngr; g0 += 64 / RT_GROUP) {
                     // big scenes: one box around the whole window first (third level of the hierarchy)
@@ -523,7 +640,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                         if (mine != 0ull) {
                             const int q = (int)__builtin_ctzll(mine);
                             mine &= mine - 1ull;
-                            const int base = P.np + CSIZE * (g0 * RT_GROUP + q);
+                            const int base = P.np + (CSIZE + 1) * (g0 * RT_GROUP + q);
                             const float4 *cs = sph + base;
                             // four records at a time: eight in flight cost 20 spilled VGPRs at 6 waves/SIMD
 #pragma unroll
@@ -549,7 +666,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
                     const bool live = slab_live(box[2 * q], box[2 * q + 1]);
                     if (COUNT && live) c_lane_clusters++;
                     if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
-                        const int base = P.np + CSIZE * q;
+                        const int base = P.np + (CSIZE + 1) * q;
                         const float4 *cs = sph + base;
 #pragma unroll
                         for (int h = 0; h < CSIZE; h += 4) {
@@ -852,6 +969,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         if (lane == 0 && c_groups) atomicAdd(&counters->groups_visited, (unsigned long long)c_groups);
         wave_add(&counters->lane_clusters, c_lane_clusters);
         wave_add(&counters->lane_groups, c_lane_groups);
+        wave_add(&counters->lane_cands, c_lane_cands);
         wave_add(&counters->group_maxpop, c_group_maxpop);
         wave_add(&counters->query_maxpop, c_query_maxpop);
         if (lane == 0) {
@@ -878,7 +996,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
 __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long *__restrict__ acc,
                                                        float *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = (float)((double)(long long)acc[i] * (1.0 / 4294967296.0));
+    if (i < n) out[i] = (float)((double)(long long)acc[i] * (1.0 / 16777216.0));
 }
 
 // launchers used by render_host.hip
@@ -886,19 +1004,21 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 // with identical results: bit 0 = no tile pool (strict one-lane-per-pixel), bit 1 = no LDS prefetch,
 // bit 3 = sphere table through the scalar cache instead of LDS (wave-level cluster votes), bit 4 = no
 // cluster culling (every sphere tested for every query: the reference's linear hittable_list scan),
-// bit 5 = wave-level cluster votes instead of per-lane cluster lists; 40 = the default algorithm with all tables in
-// global memory (chosen automatically for scenes too large for LDS)
+// bit 5 = wave-level cluster votes instead of per-lane cluster lists; bit 6 = per-lane lists found through the
+// two-level box hierarchy instead of the range tables (round 1's default); 40 = the default algorithm with all
+// tables in global memory (chosen automatically for scenes too large for LDS), 104 = the same for bit 6
 #define RT_VARIANT_TABLE(X)        \
-    X(0, true, true, false, 2)     \
-    X(1, false, true, false, 2)    \
-    X(2, true, false, false, 2)    \
+    X(0, true, true, false, 3)     \
+    X(1, false, true, false, 3)    \
     X(8, true, true, true, 1)      \
     X(16, true, true, false, 0)    \
     X(17, false, true, false, 0)   \
     X(19, false, false, false, 0)  \
     X(24, true, true, true, 0)     \
     X(32, true, true, false, 1)    \
-    X(40, true, true, true, 2)
+    X(40, true, true, true, 3)     \
+    X(64, true, true, false, 2)    \
+    X(104, true, true, true, 2)
 // every variant exists for both cluster sizes (the linear scans ignore it)
 #define RT_WITH_CSIZE(CALL8, CALL16) \
     if (cluster == 16) { CALL16; } else { CALL8; }
@@ -909,13 +1029,13 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
     const dim3 g(grid), t(256);
     const int cluster = P.cluster;
     if (counters) {
-        if (variant == 40) {
-            RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<true, true, true, true, 2, 8>), g, t, lds_bytes, stream, P, img, acc, queue, counters),
-                          hipLaunchKernelGGL((render_kernel<true, true, true, true, 2, 16>), g, t, lds_bytes, stream, P, img, acc, queue, counters))
-        } else {
-            RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<true, true, true, false, 2, 8>), g, t, lds_bytes, stream, P, img, acc, queue, counters),
-                          hipLaunchKernelGGL((render_kernel<true, true, true, false, 2, 16>), g, t, lds_bytes, stream, P, img, acc, queue, counters))
-        }
+#define RT_COUNT_LAUNCH(SCALAR, CULL)                                                                                                       \
+    RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<true, true, true, SCALAR, CULL, 8>), g, t, lds_bytes, stream, P, img, acc, queue, counters),  \
+                  hipLaunchKernelGGL((render_kernel<true, true, true, SCALAR, CULL, 16>), g, t, lds_bytes, stream, P, img, acc, queue, counters))
+        if (variant == 40) { RT_COUNT_LAUNCH(true, 3) }
+        else if (variant == 64) { RT_COUNT_LAUNCH(false, 2) }
+        else { RT_COUNT_LAUNCH(false, 3) }
+#undef RT_COUNT_LAUNCH
         return;
     }
     DevCounters *none = nullptr;
@@ -937,13 +1057,13 @@ int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster) {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
     if (count) {
-        if (variant == 40) {
-            RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, true, 2, 8>, 256, lds_bytes),
-                          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, true, 2, 16>, 256, lds_bytes))
-        } else {
-            RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, 2, 8>, 256, lds_bytes),
-                          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, false, 2, 16>, 256, lds_bytes))
-        }
+#define RT_COUNT_OCC(SCALAR, CULL)                                                                                                          \
+    RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 8>, 256, lds_bytes),   \
+                  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 16>, 256, lds_bytes))
+        if (variant == 40) { RT_COUNT_OCC(true, 3) }
+        else if (variant == 64) { RT_COUNT_OCC(false, 2) }
+        else { RT_COUNT_OCC(false, 3) }
+#undef RT_COUNT_OCC
     } else {
 #define RT_OCC(V, POOL, PRE, SCALAR, CULL)                                                                                                  \
     if (variant == V) {                                                                                                                      \
@@ -954,6 +1074,15 @@ int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster) {
 #undef RT_OCC
     }
     return (e == hipSuccess && n > 0) ? n : 4;
+}
+
+// candidate search of a variant (the CULL template argument): decides how much of the hot table is staged
+int variant_cull_mode(unsigned variant) {
+#define RT_MODE(V, POOL, PRE, SCALAR, CULL) \
+    if (variant == V) return CULL;
+    RT_VARIANT_TABLE(RT_MODE)
+#undef RT_MODE
+    return -1;
 }
 
 bool variant_exists(unsigned variant) {
@@ -985,6 +1114,8 @@ void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStr
 int set_max_dynamic_lds(size_t bytes) {
 #define RT_ATTR1(K)                                                                                                  \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+    RT_ATTR1((render_kernel<true, true, true, false, 3, 8>))
+    RT_ATTR1((render_kernel<true, true, true, false, 3, 16>))
     RT_ATTR1((render_kernel<true, true, true, false, 2, 8>))
     RT_ATTR1((render_kernel<true, true, true, false, 2, 16>))
 #define RT_ATTR(V, POOL, PRE, SCALAR, CULL)                      \

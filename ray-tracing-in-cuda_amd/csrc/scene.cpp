@@ -264,14 +264,17 @@ int scene_from_json(const char *text, size_t len, Scene &s) {
         if (!of->is_string()) r.fail("top level: \"output_file\" must be a string");
         else s.output_file = of->str;
     }
-    s.flags = RT_FLAG_DEFOCUS_BLUR;  // follow cmake-cpu-version/camera.h:34
+    // The JSON interface is gpu-version's, whose camera::get_ray has the lens sample commented out
+    // (camera.cuh:33-34: rd = 0, no draws): a scene file that does not say otherwise renders without defocus
+    // blur, like `parallel_compute -f scene.json`.  "defocus_blur": true selects cmake-cpu-version/camera.h:34.
+    s.flags = 0;
     if (const JsonValue *f = root.find("sky_gradient")) {
         if (f->kind != JsonValue::Bool) r.fail("top level: \"sky_gradient\" must be a boolean");
         else if (f->b) s.flags |= RT_FLAG_SKY_GRADIENT;
     }
     if (const JsonValue *f = root.find("defocus_blur")) {
         if (f->kind != JsonValue::Bool) r.fail("top level: \"defocus_blur\" must be a boolean");
-        else if (!f->b) s.flags &= ~RT_FLAG_DEFOCUS_BLUR;
+        else if (f->b) s.flags |= RT_FLAG_DEFOCUS_BLUR;
     }
     if (root.find("russian_roulette")) {
         const double p = r.num(root, "russian_roulette", "top level");

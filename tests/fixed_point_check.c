@@ -1,5 +1,5 @@
 /* The kernel's fp64-free sample -> 64-bit fixed point conversion (render_kernel.hip, radiance_to_fixed)
- * against the checker's definition llrint((double)v * 2^32) (oracle/rt_oracle.c, radiance_to_fixed).
+ * against the checker's definition llrint((double)v * 2^24) (oracle/rt_oracle.c, radiance_to_fixed).
  * usage: fixed_point_check <stride>   (stride 1 = every fp32 bit pattern, ~20 s) */
 #include <math.h>
 #include <stdint.h>
@@ -8,18 +8,18 @@
 #include <string.h>
 
 static uint64_t by_definition(float v) {
-    if (!(fabsf(v) <= 1e9f)) v = (v != v) ? 0.0f : copysignf(1e9f, v);
-    return (uint64_t)llrint((double)v * 4294967296.0);
+    if (!(fabsf(v) <= 65536.0f)) v = (v != v) ? 0.0f : copysignf(65536.0f, v);
+    return (uint64_t)llrint((double)v * 16777216.0);
 }
 
 /* the device expression, operation for operation (v_cvt_u32_f32 truncates, v_rndne_f32 = rintf) */
 static uint64_t as_in_the_kernel(float v) {
-    if (!(fabsf(v) <= 1e9f)) v = (v != v) ? 0.0f : copysignf(1e9f, v);
+    if (!(fabsf(v) <= 65536.0f)) v = (v != v) ? 0.0f : copysignf(65536.0f, v);
     const float a = fabsf(v);
     const uint32_t hi = (uint32_t)a;
     const float frac = a - (float)hi;
-    const uint32_t lo = (uint32_t)rintf(frac * 4294967296.0f);
-    const uint64_t m = ((uint64_t)hi << 32) | lo;
+    const uint32_t lo = (uint32_t)rintf(frac * 16777216.0f);
+    const uint64_t m = ((uint64_t)hi << 24) + lo;
     return v < 0.0f ? 0ull - m : m;
 }
 
@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
         }
         ++n;
     }
-    /* neighbourhoods of every power of two, of 1e9 and of ties at the 2^-33 boundary */
+    /* neighbourhoods of every power of two, of the clamp (2^16) and of ties at the 2^-25 boundary */
     for (int e = -40; e <= 31; ++e)
         for (int k = -4; k <= 4; ++k) {
             float v = ldexpf(1.0f, e);

@@ -119,8 +119,8 @@ def test_config2_basic_scene_and_dna_720p(rtmi, rtcheck, golden_dir):
     empty.override(width=1280, height=720, spp=256, max_depth=50)
     img = empty.render(rtmi.Opts(seed=SEED))
     bg = np.array(list(empty.info.background), dtype=np.float32)
-    # every sample is the constant background: 256 x its 2^-32 fixed-point value, converted to fp32 once
-    want = (np.rint(bg.astype(np.float64) * 2.0 ** 32) * 256 * 2.0 ** -32).astype(np.float32)
+    # every sample is the constant background: 256 x its 2^-24 fixed-point value, converted to fp32 once
+    want = (np.rint(bg.astype(np.float64) * 2.0 ** 24) * 256 * 2.0 ** -24).astype(np.float32)
     assert np.array_equal(img, np.broadcast_to(want, img.shape))
     _rows_equal_checker(rtcheck, empty, img, [(0, 1), (719, 720)])
 

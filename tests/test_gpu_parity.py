@@ -127,12 +127,13 @@ def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
     assert np.abs(acc - whole).max() <= 13 * 2.0 ** -24 * max(1.0, acc.max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 8, 16, 17, 19, 24, 32, 40])
+@pytest.mark.parametrize("variant", [0, 1, 8, 16, 17, 19, 24, 32, 40, 64, 104])
 def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir, variant):
     """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
     bit 1: unbatched sphere loop; bit 3: sphere table read through the scalar cache instead of
-    LDS; bit 4: no AABB cluster culling (the reference's linear scan).  Same bits as the checker
-    in every combination."""
+    LDS; bit 4: no AABB cluster culling (the reference's linear scan); bit 5: wave-level cluster votes;
+    bit 6: candidate clusters through the box hierarchy instead of the range tables.  Same bits as the
+    checker in every combination."""
     for name, w, h, spp in (("rtiow", 72, 40, 6), ("mixed_emissive", 50, 30, 5)):
         sc = _scene(rtmi, scenes_dir, golden_dir, name)
         sc.override(width=w, height=h, spp=spp)
@@ -272,7 +273,7 @@ def test_many_spheres_above_64k_lds(rtmi, rtcheck):
         sc.sphere(rng.uniform(-6, 6, 3), float(rng.uniform(0.05, 0.2)), mats[i % len(mats)])
     _assert_same(rtmi, rtcheck, sc)              # default: global-memory tables at this size
     _assert_same(rtmi, rtcheck, sc, variant=32)  # tables in LDS (105 KB: the raised dynamic-LDS limit)
-    _assert_same(rtmi, rtcheck, sc, variant=2)   # per-lane lists over LDS tables
+    _assert_same(rtmi, rtcheck, sc, variant=64)  # per-lane lists through the box hierarchy (global tables at this size)
 
 
 def test_full_frame_properties(rtmi, rtcheck):
@@ -306,13 +307,13 @@ def test_axis_parallel_bounce_is_not_culled(rtmi, rtcheck):
     ref, queries = rtcheck.oracle_trace_sample(osc, SEED, x, y, smp)
     assert len(queries) == 3 and queries[1][4] == 0.0 and queries[1][7] == 1.0  # dy == 0, and it hits
     rows = {}
-    for variant in (0, 1, 32, 16):
+    for variant in (0, 1, 32, 64, 16):
         o = rtmi.Opts(seed=SEED, variant=variant, sample_first=smp, sample_count=1, tile_rows=1, tile_first=y,
                       tile_stride=100000)
         rows[variant] = sc.render(o)
         assert rows[variant].shape == (1, 1920, 3)
         assert np.array_equal(rows[variant][0, x], ref), variant
-    for variant in (0, 1, 32):
+    for variant in (0, 1, 32, 64):
         assert np.array_equal(rows[variant], rows[16])
 
 
@@ -326,6 +327,7 @@ def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
         assert st.cull_cluster_size == int(forced)
         _assert_same(rtmi, rtcheck, sc)
         _assert_same(rtmi, rtcheck, sc, variant=32)
+        _assert_same(rtmi, rtcheck, sc, variant=64)
         vol = rtmi.Scene.new(64, 40, 3, 10)        # a volume: 8 by default
         vol.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
         vol.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
@@ -336,6 +338,7 @@ def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
         assert vol.count(rtmi.Opts(seed=SEED)).cull_cluster_size == int(forced)
         _assert_same(rtmi, rtcheck, vol)
         _assert_same(rtmi, rtcheck, vol, variant=40)
+        _assert_same(rtmi, rtcheck, vol, variant=104)
     monkeypatch.delenv("RTMI_CLUSTER")
     assert rtmi.Scene.rtiow(5, 32, 18, 1, 5).count(rtmi.Opts()).cull_cluster_size == 16
     vol2 = rtmi.Scene.new(16, 16, 1, 3)
@@ -376,3 +379,21 @@ def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
     assert np.array_equal(a, sc3.render(rtmi.Opts(seed=5, variant=16))) and a.max() > 0
     ref, _ = rtcheck.oracle_render(rtcheck.OracleScene(sc3), seed=5, rows=(360, 362))
     assert np.array_equal(a[360:362], ref[360:362])
+
+
+def test_bright_emitter_saturates_instead_of_wrapping(rtmi, rtcheck):
+    """A 1e7-radiance light seen directly at 1024 spp: the reference's float sum reaches 1e10 and the written pixel is
+    white.  The exact integer pixel sums must not wrap (a 2^-32 format did, at 2^31: negative sum, black pixel):
+    samples are clamped to 2^16 in a 2^-24 format and at most 2^23 samples per pixel are accepted."""
+    import test_primitives as tp
+    sc = tp._probe_scene(rtmi, bg=(0, 0, 0))
+    sc.xy_rect(-1, 1, -1, 1, 0.0, sc.diffuse_light((1e7, 3e4, 70000.0)))
+    sc.override(spp=1024)
+    img = _assert_same(rtmi, rtcheck, sc)
+    centre = img[4, 4]
+    assert np.all(centre == np.float32([65536.0 * 1024, 3e4 * 1024, 65536.0 * 1024]))  # clamp, exact, clamp
+    assert np.all(rtmi.quantize_rgb8(img, 1024)[4, 4] == 255)
+    with pytest.raises(rtmi.RtmiError) as e:
+        sc.render(rtmi.Opts(sample_first=(1 << 23) - 5, sample_count=6))
+    assert e.value.status == 6 and "samples per pixel" in str(e.value)
+    assert sc.render(rtmi.Opts(sample_first=(1 << 23) - 6, sample_count=6)).shape == img.shape

@@ -14,9 +14,9 @@ RTMI_BIN = os.path.join(ROOT, "ray-tracing-in-cuda_amd", "rtmi")
 
 
 def test_acc_to_rgb_is_one_rounding_of_the_exact_sum(rtmi):
-    acc = np.array([0, 1 << 32, -(1 << 32), 3 << 31, (1 << 32) + 1, 12345678901234567, -7], dtype=np.int64)
+    acc = np.array([0, 1 << 24, -(1 << 24), 3 << 23, (1 << 24) + 1, 12345678901234567, -7], dtype=np.int64)
     got = rtmi.acc_to_rgb(acc)
-    want = (acc.astype(np.float64) / 4294967296.0).astype(np.float32)  # exact in double below 2^53
+    want = (acc.astype(np.float64) / 16777216.0).astype(np.float32)  # exact in double below 2^53
     assert got.dtype == np.float32 and np.array_equal(got, want)
     assert got[1] == 1.0 and got[2] == -1.0 and got[3] == 1.5
 

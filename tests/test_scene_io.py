@@ -261,3 +261,26 @@ def test_aabb_slab(rtmi, rtcheck):
         inside = np.all((pts >= lo - 1e-6) & (pts <= hi + 1e-6), axis=1).any()
         if inside:
             assert a
+
+
+def test_json_scenes_default_to_gpu_version_camera(rtmi, golden_dir):
+    """The JSON interface is gpu-version's: its camera::get_ray has the lens sample disabled (camera.cuh:33-34) and
+    misses return the constant background (main.cu:63).  A scene file without the two extension keys must select
+    exactly that; the keys switch the cmake-cpu-version behaviour on."""
+    import json
+    d = json.load(open(os.path.join(golden_dir, "scenes", "sample_scene.json")))
+    d.pop("defocus_blur", None), d.pop("sky_gradient", None)
+    assert d["camera"]["aperture"] > 0  # the reference's files all carry an aperture the CUDA renderer ignores
+    plain = rtmi.Scene.parse(json.dumps(d))
+    assert plain.info.flags == 0
+    d["defocus_blur"] = True
+    assert rtmi.Scene.parse(json.dumps(d)).info.flags == rtmi.FLAG_DEFOCUS_BLUR
+    d["sky_gradient"] = True
+    assert rtmi.Scene.parse(json.dumps(d)).info.flags == rtmi.FLAG_DEFOCUS_BLUR | rtmi.FLAG_SKY_GRADIENT
+    # the writer always states both, so a round trip never depends on the default
+    again = rtmi.Scene.parse(plain.to_json())
+    assert again.info.flags == 0 and '"defocus_blur": false' in plain.to_json()
+    # the CPU-semantics entry points keep the lens: random_scene() and the constructors
+    assert rtmi.Scene.rtiow(7, 32, 18, 1, 5).info.flags == rtmi.FLAG_DEFOCUS_BLUR | rtmi.FLAG_SKY_GRADIENT
+    assert rtmi.Scene.new(16, 16, 1).info.flags == rtmi.FLAG_DEFOCUS_BLUR | rtmi.FLAG_SKY_GRADIENT
+    assert rtmi.Scene.dna(0.0).info.flags == 0  # dna.py renders through gpu-version
