@@ -51,6 +51,17 @@
 #define RT_WAVES_PER_SIMD 7
 #endif
 // the flat-scan ablation kernels (CULL == 0) keep two register sets of sphere records in flight
+// an item is retired (its LDS accumulator flushed and reused) once at most this many of its paths are still alive
+#ifndef RT_ORPHAN_MAX
+#define RT_ORPHAN_MAX 16
+#endif
+// MEASUREMENT ONLY (wrong images; never defined by the Makefile): what a section costs is what the frame gains when it
+// is cut out -- RT_ABLATE=1 rejection loops accept their first candidate, 2 no pixel accumulation, 4 the sample
+// seeding skips Philox, 8 no shading of hits (every hit ends the path)
+#ifndef RT_ABLATE
+#define RT_ABLATE 0
+#endif
+#define RT_ABLATE_REJ(cond) ((RT_ABLATE & 1) ? false : (cond))
 #ifndef RT_WAVES_LINEAR
 #define RT_WAVES_LINEAR RT_WAVES_PER_SIMD
 #endif
@@ -66,7 +77,11 @@ struct LaneRng {
 };
 
 __device__ __forceinline__ void rng_start(LaneRng &r, uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1) {
+#if defined(RT_ABLATE) && (RT_ABLATE & 4)
+    r.g.x = pixel * 2654435761u, r.g.y = sample * 40503u + 1u, r.g.z = k0 ^ pixel, r.g.w = k1 + sample + 7u;
+#else
     r.g = xor128_seed(pixel, sample, k0, k1);
+#endif
 }
 
 template <bool COUNT>
@@ -77,8 +92,12 @@ __device__ __forceinline__ float rng_next(LaneRng &r) {
 }
 
 template <bool COUNT>
-__device__ __forceinline__ float rng_pm1(LaneRng &r) {  // random_double(-1, 1): -1 + 2 xi, exact
-    return -1.0f + 2.0f * rng_next<COUNT>(r);
+__device__ __forceinline__ float rng_pm1(LaneRng &r) {  // random_double(-1, 1): -1 + 2 xi
+    // xi = k 2^-24 with a 24-bit integer k: 2 xi and -1 + 2 xi are exact in fp32 (multiples of 2^-23 in [-1, 1)), so
+    // one fused multiply-add returns the very value of the checker's three operations (convert, scale, shift)
+    const uint32_t w = xor128_next(r.g);
+    if (COUNT) r.draws++;
+    return fmaf((float)(w >> 8), 1.0f / 8388608.0f, -1.0f);
 }
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -221,20 +240,26 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         hy = (tile_first + htl * tile_stride) * tile_rows + (hlr - htl * tile_rows);
         hvalid = (hx < P.width && hlr < local_rows && hy < P.height) ? 1 : 0;
     };
-    // tile accumulator -> global accumulators (image[y*W + x] += res, main.cu:104; one 64-bit atomic per
-    // channel: other sample chunks of the same pixels are other work items), then clear it for reuse
+    // tile accumulator -> global accumulators (image[y*W + x] += res, main.cu:104; other sample chunks of the same
+    // pixels are other work items, hence atomics), then clear it for reuse.  The tile's 192 sums lie in LDS as
+    // [row][column][channel], which is also the order of a tile row in the global plane (24 consecutive 64-bit
+    // words): lane l adds the words l, 64 + l and 128 + l, so one instruction covers 512 contiguous bytes of LDS and
+    // 2 2/3 tile rows of 192 contiguous bytes in memory (the atomics execute memory-side in 64-byte requests: with
+    // one pixel per lane -- 24 bytes apart -- every request carried 8 useful bytes).  Words that are zero are
+    // skipped: black samples, and the pixels of a ragged tile outside the image or the shard, which never receive a
+    // sample -- so no bounds logic is needed here.
     auto flush_tile = [&](unsigned long long *tile, int x0, int band) {
-        int hx, hlr, hy, hvalid;
-        home_pixel(x0, band, hx, hlr, hy, hvalid);
         __builtin_amdgcn_wave_barrier();
-        unsigned long long *a = tile + lane * 3;
-        if (hvalid) {
-            unsigned long long *g = acc + ((size_t)hlr * P.width + hx) * 3;
-            atomicAdd(g + 0, a[0]);
-            atomicAdd(g + 1, a[1]);
-            atomicAdd(g + 2, a[2]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = j * 64 + lane;
+            const unsigned long long v = tile[k];
+            if (v != 0ull) {
+                const int row = k / 24, rem = k - row * 24;
+                atomicAdd(acc + ((size_t)(band * 8 + row) * P.width + x0) * 3 + rem, v);
+                tile[k] = 0ull;
+            }
         }
-        a[0] = a[1] = a[2] = 0ull;
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -260,14 +285,22 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
         }
         // The pool is handed out and idle lanes want the next item: retire the current one.  Its
-        // accumulator is flushed for reuse and every path still alive becomes an orphan.
-        if (c_valid && idle != 0ull && exhausted && !queue_empty) {
-            if (active && slot == -2) slot = (c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7);
-            flush_tile(c_acc, c_x0, c_band);
-            c_valid = false;
+        // accumulator is flushed for reuse and every path still alive becomes an orphan (three scattered 64-bit
+        // global atomics when it ends: 64-byte memory-side requests for 8 useful bytes each).  So the item is only
+        // retired once at most RT_ORPHAN_MAX paths are left: the idle lanes wait the two or three iterations that
+        // takes (paths last 2.7 queries on average, an item hundreds of iterations).
+        bool fetch = exhausted && !queue_empty;
+        if (c_valid && idle != 0ull && fetch) {
+            if (__popcll(~idle) <= RT_ORPHAN_MAX) {
+                if (active && slot == -2) slot = (c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7);
+                flush_tile(c_acc, c_x0, c_band);
+                c_valid = false;
+            } else {
+                fetch = false;
+            }
         }
         if (idle) {  // wave-uniform
-            if (exhausted && !queue_empty) {
+            if (fetch) {
                 unsigned int item = 0;
                 if (lane == 0) item = atomicAdd(queue, 1u);
                 item = __builtin_amdgcn_readfirstlane(item);
@@ -338,7 +371,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     do {  // random_in_unit_disk, vec3.h:157-165
                         px = rng_pm1<COUNT>(rng);
                         py = rng_pm1<COUNT>(rng);
-                    } while (fmaf(px, px, py * py) >= 1.0f);
+                    } while (RT_ABLATE_REJ(fmaf(px, px, py * py) >= 1.0f));
                     const float4 c_u = cv[4], c_v = cv[5];
                     float rdx = c_org.w * px, rdy = c_org.w * py;
                     offx = fmaf(c_u.x, rdx, c_v.x * rdy);
@@ -844,7 +877,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         sy = rng_pm1<COUNT>(rng);
                         sz = rng_pm1<COUNT>(rng);
                         sl2 = dot3(sx, sy, sz, sx, sy, sz);
-                    } while (sl2 >= 1.0f);
+                    } while (RT_ABLATE_REJ(sl2 >= 1.0f));
                 }
 
                 float ndx, ndy, ndz;           // scattered direction
@@ -929,17 +962,19 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 if (COUNT) c_misses++;
             }
             tick(3);
-            if (path_done) {  // res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
+            if (path_done && (RT_ABLATE & 2)) active = false;
+            if (path_done && !(RT_ABLATE & 2)) {  // res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
+                const unsigned long long fr = radiance_to_fixed(L_r), fg = radiance_to_fixed(L_g), fb = radiance_to_fixed(L_b);
                 if (slot >= 0) {
                     unsigned long long *g = acc + (size_t)slot * 3;
-                    atomicAdd(g + 0, radiance_to_fixed(L_r));
-                    atomicAdd(g + 1, radiance_to_fixed(L_g));
-                    atomicAdd(g + 2, radiance_to_fixed(L_b));
+                    if (fr) atomicAdd(g + 0, fr);
+                    if (fg) atomicAdd(g + 1, fg);
+                    if (fb) atomicAdd(g + 2, fb);
                 } else {
                     unsigned long long *a = c_acc + cur_p * 3;
-                    atomicAdd(a + 0, radiance_to_fixed(L_r));
-                    atomicAdd(a + 1, radiance_to_fixed(L_g));
-                    atomicAdd(a + 2, radiance_to_fixed(L_b));
+                    atomicAdd(a + 0, fr);
+                    atomicAdd(a + 1, fg);
+                    atomicAdd(a + 2, fb);
                 }
                 active = false;
             }

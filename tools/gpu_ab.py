@@ -1,13 +1,25 @@
-"""A/B of two builds in ONE process order: alternate processes are needed (one library per process), so this
-script times one library (RTMI_LIB) for a few repetitions; run it alternately from the shell."""
-import os, sys
+"""A/B of alternative builds of the library (RTMI_LIB) on one variant (run on the GPU box).
+usage: gpu_ab.py <spp> <variant> <lib.so> [<lib.so> ...]     ('-' = the in-tree library)"""
+import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from __graft_entry__ import load_package
-rtmi = load_package()
-spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-sc = rtmi.Scene.rtiow(7, 1920, 1080, spp, 50)
-ts = []
-for rep in range(4):
-    st = rtmi.Stats(); sc.render(rtmi.Opts(seed=2023), st); ts.append(st.kernel_ms)
-print(os.path.basename(os.environ.get("RTMI_LIB", "librtmi.so (tree)")), " ".join(f"{t:.2f}" for t in ts), flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    rtmi = load_package()
+    spp, variant = int(sys.argv[2]), int(sys.argv[3])
+    sc = rtmi.Scene.rtiow(7, 1920, 1080, spp, 50)
+    o = rtmi.Opts(seed=2023, variant=variant)
+    sc.render(o)
+    ms = []
+    for _ in range(3):
+        st = rtmi.Stats(); sc.render(o, st); ms.append(st.kernel_ms)
+    print(f"{os.environ.get('RTMI_LIB', 'in-tree')}: variant {variant} {spp} spp: best {min(ms):.2f} ms, all {[round(m, 2) for m in ms]}", flush=True)
+else:
+    spp, variant = sys.argv[1], sys.argv[2]
+    for lib in sys.argv[3:]:
+        env = dict(os.environ)
+        if lib != "-":
+            env["RTMI_LIB"] = os.path.join(ROOT, lib)
+        else:
+            env.pop("RTMI_LIB", None)
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child", spp, variant], env=env, check=True)

@@ -27,7 +27,7 @@ for case in range(n_cases):
     chunk = int(rng.choice([0, 0, 1, 3, 7, 8, 16, 17, 32, 50, 64, 128]))
     tile_rows = int(rng.choice([1, 3, 8, 8, 16]))
     stride = int(rng.integers(1, 6)); tf = int(rng.integers(0, stride))
-    variant = int(rng.choice([0, 0, 0, 1, 2, 32, 40]))
+    variant = int(rng.choice([0, 0, 0, 1, 64, 32, 40]))
     o = rtmi.Opts(seed=int(rng.integers(0, 2**31)), sample_first=first, sample_count=count, spp_chunk=chunk,
                   tile_rows=tile_rows, tile_first=tf, tile_stride=stride, variant=variant)
     rows = sc.shard_global_rows(o)
