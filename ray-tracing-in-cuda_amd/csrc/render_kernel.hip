@@ -272,155 +272,25 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     int cur_p = lane;  // tile-local pixel of the path this lane is tracing
     bool active = false;
 
+    // One iteration of the main loop:
+    //   (1) closest-hit query of every live lane              hittable_list::hit
+    //   (2) hit record + material of the winner; a miss or an emitter ends the path here
+    //   (3) pixel accumulation of the paths that ended
+    //   (4) refill: idle lanes take the next (pixel, sample) of the tile's pool, seed their stream, draw the jitter
+    //   (5) ONE rejection loop for both kinds of lanes: random_in_unit_sphere for the scatter step of a lambertian /
+    //       metal hit (three draws per attempt) and random_in_unit_disk for the lens sample of a new path (two)
+    //   (6) the scatter step (lambertian / metal / dielectric) | the camera ray, then what both share: |d|^2, 1 / |d|^2
+    // The loops of (5) cost max-over-lanes attempts each; as two loops (one inside the refill, one inside the shading)
+    // they took 13 % of the frame (measured by cutting them out, RT_ABLATE=1).
+    bool ended = false;  // this lane's path ended in step (6) of the previous iteration: its sample is added in (3)
     for (;;) {
         tick(5);
-        // ---- refill: lanes without a live path take new samples
-        // (render()'s sample loop, main.cu:95-101; camera::get_ray camera.h:32-39)
-        const bool need = !active;
-        const unsigned long long idle = __ballot(need);
-        // is the current item handed out completely?
-        bool exhausted = !c_valid;
-        if (c_valid) {
-            if (POOL) exhausted = cursor >= c_pool;
-            else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
-        }
-        // The pool is handed out and idle lanes want the next item: retire the current one.  Its
-        // accumulator is flushed for reuse and every path still alive becomes an orphan (three scattered 64-bit
-        // global atomics when it ends: 64-byte memory-side requests for 8 useful bytes each).  So the item is only
-        // retired once at most RT_ORPHAN_MAX paths are left: the idle lanes wait the two or three iterations that
-        // takes (paths last 2.7 queries on average, an item hundreds of iterations).
-        bool fetch = exhausted && !queue_empty;
-        if (c_valid && idle != 0ull && fetch) {
-            if (__popcll(~idle) <= RT_ORPHAN_MAX) {
-                if (active && slot == -2) slot = (c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7);
-                flush_tile(c_acc, c_x0, c_band);
-                c_valid = false;
-            } else {
-                fetch = false;
-            }
-        }
-        if (idle) {  // wave-uniform
-            if (fetch) {
-                unsigned int item = 0;
-                if (lane == 0) item = atomicAdd(queue, 1u);
-                item = __builtin_amdgcn_readfirstlane(item);
-                const int4 ia = ipar4(0), ib = ipar4(1), ic = ipar4(2);
-                if (item >= (unsigned int)ia.z) {
-                    queue_empty = true;  // the counter only grows: every wave gets here
-                    if (COUNT) t_qe = __builtin_amdgcn_s_memrealtime();
-                } else {
-                    const unsigned int tiles_x = (unsigned int)ia.x, bands = (unsigned int)ia.y;
-                    const int sample_first = ia.w, sample_count = ib.x, spp_chunk = ib.y;
-                    const int n_big = ib.z, n_med = ib.w, q_med = ic.x, q_small = ic.y;
-                    c_x0 = (int)(item % tiles_x) * 8;
-                    c_band = (int)((item / tiles_x) % bands);
-                    const int chunk = (int)(item / (tiles_x * bands));
-                    int s_stop;  // sample range: big chunks first, shorter and shorter ones towards the end of the queue
-                    if (chunk < n_big) {
-                        c_sbegin = sample_first + chunk * spp_chunk;
-                        s_stop = c_sbegin + spp_chunk;
-                    } else if (chunk < n_big + n_med) {
-                        c_sbegin = sample_first + n_big * spp_chunk + (chunk - n_big) * q_med;
-                        s_stop = c_sbegin + q_med;
-                    } else {
-                        c_sbegin = sample_first + n_big * spp_chunk + n_med * q_med + (chunk - n_big - n_med) * q_small;
-                        s_stop = c_sbegin + q_small;
-                    }
-                    const int s_end = sample_first + sample_count;
-                    if (s_stop > s_end) s_stop = s_end;
-                    c_pool = (s_stop - c_sbegin) * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
-                    cursor = 0;
-                    mine = 0;
-                    c_valid = true;
-                    int hx_unused, hlr_unused;
-                    home_pixel(c_x0, c_band, hx_unused, hlr_unused, c_hy, c_hvalid);
-                }
-            }
-            bool start = false;
-            int sp = 0, spx = 0, spy = 0, ss = 0;
-            if (POOL) {
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                const int k = cursor + rank;
-                if (c_valid) cursor = min(cursor + (int)__popcll(idle), c_pool);
-                sp = k & 63;
-                // row and validity of pixel sp live in lane sp's registers (all lanes take part)
-                spy = __shfl(c_hy, sp, 64);
-                const int pv = __shfl(c_hvalid, sp, 64);
-                spx = c_x0 + (sp & 7);
-                ss = c_sbegin + (k >> 6);
-                start = need && c_valid && k < c_pool && pv != 0;
-            } else {
-                start = need && c_valid && mine * 64 < c_pool && c_hvalid != 0;
-                sp = lane, spx = c_x0 + (lane & 7), spy = c_hy, ss = c_sbegin + mine;
-                if (start) mine++;
-            }
-            if (start) {
-                cur_p = sp;
-                slot = -2;
-                rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss, k0, k1);
-                float u = ((float)spx + rng_next<COUNT>(rng)) / wm1;
-                float v = ((float)spy + rng_next<COUNT>(rng)) / hm1;
-                float offx = 0.0f, offy = 0.0f, offz = 0.0f;
-                // the camera's derived vectors come from the hot table (wave-uniform reads, used here only),
-                // not from kernel arguments that would sit in SGPRs for the whole launch
-                const float4 *cv = hot + P.off_cam;
-                const float4 c_org = cv[0];  // origin, lens_radius
-                if (P.flags & RT_FLAG_DEFOCUS_BLUR) {
-                    float px, py;
-                    do {  // random_in_unit_disk, vec3.h:157-165
-                        px = rng_pm1<COUNT>(rng);
-                        py = rng_pm1<COUNT>(rng);
-                    } while (RT_ABLATE_REJ(fmaf(px, px, py * py) >= 1.0f));
-                    const float4 c_u = cv[4], c_v = cv[5];
-                    float rdx = c_org.w * px, rdy = c_org.w * py;
-                    offx = fmaf(c_u.x, rdx, c_v.x * rdy);
-                    offy = fmaf(c_u.y, rdx, c_v.y * rdy);
-                    offz = fmaf(c_u.z, rdx, c_v.z * rdy);
-                }
-                const float4 c_ll = cv[1], c_hor = cv[2], c_ver = cv[3];
-                dx = fmaf(v, c_ver.x, fmaf(u, c_hor.x, c_ll.x));
-                dy = fmaf(v, c_ver.y, fmaf(u, c_hor.y, c_ll.y));
-                dz = fmaf(v, c_ver.z, fmaf(u, c_hor.z, c_ll.z));
-                dx = (dx - c_org.x) - offx;
-                dy = (dy - c_org.y) - offy;
-                dz = (dz - c_org.z) - offz;
-                ox = c_org.x + offx;
-                oy = c_org.y + offy;
-                oz = c_org.z + offz;
-                ra = dot3(dx, dy, dz, dx, dy, dz);
-                rinv_a = 1.0f / ra;
-                beta_r = beta_g = beta_b = 1.0f;
-                L_r = L_g = L_b = 0.0f;
-                depth = P.max_depth;
-                active = true;
-                if (COUNT) c_samples++;
-                // Russian roulette before the first query (4_0_path_tracing.py:45-46): a sample that does
-                // not survive is black -- nothing to trace, nothing to add
-                // (a survivor's throughput is divided by p at once: include/rtmi.h, rt_scene_set_russian_roulette)
-                if (P.rr_p > 0.0f) {
-                    if (rng_next<COUNT>(rng) > P.rr_p) active = false;
-                    beta_r = beta_g = beta_b = 1.0f / P.rr_p;
-                }
-            }
-        }
-        tick(0);
-        if (!__any(active)) {
-            // nothing in flight.  Out of work when the queue is
-            // dry and the current item is handed out; otherwise loop: the refill above makes progress
-            // every time (takes an item, marks the queue empty, or skips off-image pool entries).
-            bool exhausted = !c_valid;
-            if (c_valid) {
-                if (POOL) exhausted = cursor >= c_pool;
-                else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
-            }
-            if (queue_empty && exhausted) {
-                if (c_valid) flush_tile(c_acc, c_x0, c_band);
-                break;
-            }
-            continue;
-        }
-
+        bool path_done = false;
+        // the winner's hit record, kept for the scatter step
+        float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, inv_len = 0;
+        int mat = 0, kind = -1;  // kind >= 0: a scatter step is due in (6)
+        bool front = false;
+        if (__any(active)) {
         if (active) {
             // ---- closest-hit query over the LDS-resident list (hittable_list::hit,
             // object.cuh:23-37).  Wave-uniform trip counts; `best_id` is the grouped id.
@@ -805,15 +675,11 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             }
 
             tick(2);
-            // ---- shade the winner (ray_color body, main.cu:45-65 / main.cpp:22-38)
-            bool path_done = false;
+            // ---- (2) the winner (ray_color body, main.cu:45-65 / main.cpp:22-38)
             // 1/|d| once per query (metal, dielectric and the sky all normalise the direction)
-            const float inv_len = 1.0f / sqrtf(ra);
+            inv_len = 1.0f / sqrtf(ra);
             if (best_id >= 0) {
                 // hit record of the winner only (the reference fills one per candidate)
-                float px, py, pz, nx, ny, nz;
-                int mat;
-                bool front;
                 if (best_id < ns) {
                     const float4 s = sph[best_id];
                     const float4 cold = image[P.off_sph_cold + best_id];
@@ -858,8 +724,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 }
 
                 const float4 *M = image + P.off_mat + 3 * mat;
-                const float4 q0 = M[0], q1 = M[1], q2 = M[2];
-                const int kind = __float_as_int(q0.x);
+                kind = __float_as_int(M[0].x);
                 if (COUNT) {
                     c_hits++;
                     if (kind <= MK_LAMBERT_CHECKER) c_scatter0++;
@@ -867,19 +732,181 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     else if (kind == MK_DIELECTRIC) c_scatter2++;
                     else c_scatter3++;
                 }
-
-                // random_in_unit_sphere (vec3.h:121-129) for every lane whose material
-                // needs one (lambertian, metal): one converged rejection loop
-                float sx = 0, sy = 0, sz = 0, sl2 = 1;
-                if (kind <= MK_METAL) {
-                    do {
-                        sx = rng_pm1<COUNT>(rng);
-                        sy = rng_pm1<COUNT>(rng);
-                        sz = rng_pm1<COUNT>(rng);
-                        sl2 = dot3(sx, sy, sz, sx, sy, sz);
-                    } while (RT_ABLATE_REJ(sl2 >= 1.0f));
+                if (kind >= MK_LIGHT_SOLID) {  // diffuse_light: emitted, never scatters (material.cuh:161-182, main.cu:48-58)
+                    const float4 q1 = M[1], q2 = M[2];
+                    const bool odd = kind == MK_LIGHT_CHECKER && checker_odd(px, py, pz);
+                    const float er = odd ? q2.x : q1.x, eg = odd ? q2.y : q1.y, eb = odd ? q2.z : q1.z;
+                    L_r = fmaf(er, beta_r, L_r), L_g = fmaf(eg, beta_g, L_g), L_b = fmaf(eb, beta_b, L_b);
+                    path_done = true;  // absorbed: main.cu:55-58
+                    kind = -1;
                 }
-
+            } else {
+                // miss: main.cpp:36-38 (sky) or main.cu:63 (constant background)
+                float bg_r, bg_g, bg_b;
+                if (P.flags & RT_FLAG_SKY_GRADIENT) {
+                    const float t = 0.5f * (inv_len * dy + 1.0f);
+                    const float omt = 1.0f - t;
+                    bg_r = fmaf(t, 0.5f, omt), bg_g = fmaf(t, 0.7f, omt), bg_b = fmaf(t, 1.0f, omt);
+                } else {
+                    bg_r = P.background[0], bg_g = P.background[1], bg_b = P.background[2];
+                }
+                L_r = fmaf(beta_r, bg_r, L_r), L_g = fmaf(beta_g, bg_g, L_g), L_b = fmaf(beta_b, bg_b, L_b);
+                path_done = true;
+                if (COUNT) c_misses++;
+            }
+          }
+        }
+        tick(3);
+        // ---- (3) res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile; also for the lanes whose
+        // path ended in the scatter step of the previous iteration (absorbed by a metal, depth used up, roulette)
+        if (path_done || ended) {
+            if (!(RT_ABLATE & 2)) {
+                const unsigned long long fr = radiance_to_fixed(L_r), fg = radiance_to_fixed(L_g), fb = radiance_to_fixed(L_b);
+                if (slot >= 0) {
+                    unsigned long long *g = acc + (size_t)slot * 3;
+                    if (fr) atomicAdd(g + 0, fr);
+                    if (fg) atomicAdd(g + 1, fg);
+                    if (fb) atomicAdd(g + 2, fb);
+                } else {
+                    unsigned long long *a = c_acc + cur_p * 3;
+                    atomicAdd(a + 0, fr);
+                    atomicAdd(a + 1, fg);
+                    atomicAdd(a + 2, fb);
+                }
+            }
+            active = false;
+            ended = false;
+        }
+        tick(4);
+        // ---- (4) refill: lanes without a live path take new samples
+        // (render()'s sample loop, main.cu:95-101; camera::get_ray camera.h:32-39)
+        float u = 0, v = 0;    // jitter of the sample a lane starts (main.cu:96-97)
+        bool started = false;  // this lane starts a new path in this iteration
+        const bool need = !active;
+        const unsigned long long idle = __ballot(need);
+        // is the current item handed out completely?
+        bool exhausted = !c_valid;
+        if (c_valid) {
+            if (POOL) exhausted = cursor >= c_pool;
+            else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
+        }
+        // The pool is handed out and idle lanes want the next item: retire the current one.  Its
+        // accumulator is flushed for reuse and every path still alive becomes an orphan (three scattered 64-bit
+        // global atomics when it ends: 64-byte memory-side requests for 8 useful bytes each).  So the item is only
+        // retired once at most RT_ORPHAN_MAX paths are left: the idle lanes wait the two or three iterations that
+        // takes (paths last 2.7 queries on average, an item hundreds of iterations).
+        bool fetch = exhausted && !queue_empty;
+        if (c_valid && idle != 0ull && fetch) {
+            if (__popcll(~idle) <= RT_ORPHAN_MAX) {
+                if (active && slot == -2) slot = (c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7);
+                flush_tile(c_acc, c_x0, c_band);
+                c_valid = false;
+            } else {
+                fetch = false;
+            }
+        }
+        if (idle) {  // wave-uniform
+            if (fetch) {
+                unsigned int item = 0;
+                if (lane == 0) item = atomicAdd(queue, 1u);
+                item = __builtin_amdgcn_readfirstlane(item);
+                const int4 ia = ipar4(0), ib = ipar4(1), ic = ipar4(2);
+                if (item >= (unsigned int)ia.z) {
+                    queue_empty = true;  // the counter only grows: every wave gets here
+                    if (COUNT) t_qe = __builtin_amdgcn_s_memrealtime();
+                } else {
+                    const unsigned int tiles_x = (unsigned int)ia.x, bands = (unsigned int)ia.y;
+                    const int sample_first = ia.w, sample_count = ib.x, spp_chunk = ib.y;
+                    const int n_big = ib.z, n_med = ib.w, q_med = ic.x, q_small = ic.y;
+                    c_x0 = (int)(item % tiles_x) * 8;
+                    c_band = (int)((item / tiles_x) % bands);
+                    const int chunk = (int)(item / (tiles_x * bands));
+                    int s_stop;  // sample range: big chunks first, shorter and shorter ones towards the end of the queue
+                    if (chunk < n_big) {
+                        c_sbegin = sample_first + chunk * spp_chunk;
+                        s_stop = c_sbegin + spp_chunk;
+                    } else if (chunk < n_big + n_med) {
+                        c_sbegin = sample_first + n_big * spp_chunk + (chunk - n_big) * q_med;
+                        s_stop = c_sbegin + q_med;
+                    } else {
+                        c_sbegin = sample_first + n_big * spp_chunk + n_med * q_med + (chunk - n_big - n_med) * q_small;
+                        s_stop = c_sbegin + q_small;
+                    }
+                    const int s_end = sample_first + sample_count;
+                    if (s_stop > s_end) s_stop = s_end;
+                    c_pool = (s_stop - c_sbegin) * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
+                    cursor = 0;
+                    mine = 0;
+                    c_valid = true;
+                    int hx_unused, hlr_unused;
+                    home_pixel(c_x0, c_band, hx_unused, hlr_unused, c_hy, c_hvalid);
+                }
+            }
+            bool start = false;
+            int sp = 0, spx = 0, spy = 0, ss = 0;
+            if (POOL) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const int k = cursor + rank;
+                if (c_valid) cursor = min(cursor + (int)__popcll(idle), c_pool);
+                sp = k & 63;
+                // row and validity of pixel sp live in lane sp's registers (all lanes take part)
+                spy = __shfl(c_hy, sp, 64);
+                const int pv = __shfl(c_hvalid, sp, 64);
+                spx = c_x0 + (sp & 7);
+                ss = c_sbegin + (k >> 6);
+                start = need && c_valid && k < c_pool && pv != 0;
+            } else {
+                start = need && c_valid && mine * 64 < c_pool && c_hvalid != 0;
+                sp = lane, spx = c_x0 + (lane & 7), spy = c_hy, ss = c_sbegin + mine;
+                if (start) mine++;
+            }
+            if (start) {
+                cur_p = sp;
+                slot = -2;
+                rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss, k0, k1);
+                u = ((float)spx + rng_next<COUNT>(rng)) / wm1;
+                v = ((float)spy + rng_next<COUNT>(rng)) / hm1;
+                if (COUNT) c_samples++;
+            }
+            started = start;
+        }
+        tick(0);
+        if (!__any(active || started)) {
+            // nothing in flight.  Out of work when the queue is dry, the current item is handed out and no sample
+            // waits to be added; otherwise loop: the refill above makes progress every time (takes an item,
+            // marks the queue empty, or skips off-image pool entries).
+            bool exhausted = !c_valid;
+            if (c_valid) {
+                if (POOL) exhausted = cursor >= c_pool;
+                else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
+            }
+            if (queue_empty && exhausted && !__any(ended)) {
+                if (c_valid) flush_tile(c_acc, c_x0, c_band);
+                break;
+            }
+            continue;
+        }
+        // ---- (5) rejection sampling, one converged loop: random_in_unit_sphere (vec3.h:121-129: three draws, for the
+        // lanes whose material scatters with one: lambertian, metal) and random_in_unit_disk (vec3.h:157-165: two
+        // draws, for the lens sample of the paths that start)
+        const bool need_s = kind >= 0 && kind <= MK_METAL;
+        const bool need_d = started && (P.flags & RT_FLAG_DEFOCUS_BLUR) != 0u;
+        float sx = 0, sy = 0, sz = 0, sl2 = 1;
+        if (need_s || need_d) {
+            do {
+                sx = rng_pm1<COUNT>(rng);
+                sy = rng_pm1<COUNT>(rng);
+                sz = 0.0f;
+                if (need_s) sz = rng_pm1<COUNT>(rng);
+                sl2 = dot3(sx, sy, sz, sx, sy, sz);  // disk: fma(x, x, y * y) -- the product with sz = 0 adds an exact zero
+            } while (RT_ABLATE_REJ(sl2 >= 1.0f));
+        }
+        // ---- (6a) the scatter step of the paths that go on
+        bool fresh = false;  // this lane has a new ray
+        if (kind >= 0) {
+            const float4 *M = image + P.off_mat + 3 * mat;
+            const float4 q0 = M[0], q1 = M[1], q2 = M[2];
                 float ndx, ndy, ndz;           // scattered direction
                 float at_r, at_g, at_b;        // attenuation
                 bool scattered = true;
@@ -897,7 +924,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     ndx = fmaf(q0.y, sx, rx), ndy = fmaf(q0.y, sy, ry), ndz = fmaf(q0.y, sz, rz);
                     at_r = q1.x, at_g = q1.y, at_b = q1.z;
                     scattered = dot3(ndx, ndy, ndz, nx, ny, nz) > 0.0f;
-                } else if (kind == MK_DIELECTRIC) {  // dielectric::scatter, material.h:66-95
+                } else {  // dielectric::scatter, material.h:66-95
                     const float ratio = front ? q0.z : q0.y;
                     const float ux = inv_len * dx, uy = inv_len * dy, uz = inv_len * dz;
                     const float udn = dot3(ux, uy, uz, nx, ny, nz);
@@ -922,64 +949,67 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         ndx = fmaf(kk, nx, ppx), ndy = fmaf(kk, ny, ppy), ndz = fmaf(kk, nz, ppz);
                     }
                     at_r = at_g = at_b = 1.0f;
-                } else {  // diffuse_light: emitted, never scatters (material.cuh:161-182, main.cu:48-58)
-                    const bool odd = kind == MK_LIGHT_CHECKER && checker_odd(px, py, pz);
-                    const float er = odd ? q2.x : q1.x, eg = odd ? q2.y : q1.y, eb = odd ? q2.z : q1.z;
-                    L_r = fmaf(er, beta_r, L_r), L_g = fmaf(eg, beta_g, L_g), L_b = fmaf(eb, beta_b, L_b);
-                    scattered = false;
-                    ndx = ndy = ndz = 0.0f;
-                    at_r = at_g = at_b = 0.0f;
                 }
 
-                if (scattered) {
-                    beta_r *= at_r, beta_g *= at_g, beta_b *= at_b;
-                    ox = px, oy = py, oz = pz;
-                    dx = ndx, dy = ndy, dz = ndz;
-                    ra = dot3(dx, dy, dz, dx, dy, dz);
-                    rinv_a = 1.0f / ra;
-                    depth--;
-                    path_done = depth <= 0;  // main.cpp:42 / main.cu:69
-                    // Russian roulette before the next query: the path keeps what it has collected
-                    if (P.rr_p > 0.0f && !path_done) {
-                        if (rng_next<COUNT>(rng) > P.rr_p) path_done = true;
-                        beta_r = beta_r / P.rr_p, beta_g = beta_g / P.rr_p, beta_b = beta_b / P.rr_p;
-                    }
-                } else {
-                    path_done = true;  // absorbed: main.cpp:32 / main.cu:55-58
-                }
+            if (scattered) {
+                beta_r *= at_r, beta_g *= at_g, beta_b *= at_b;
+                ox = px, oy = py, oz = pz;
+                dx = ndx, dy = ndy, dz = ndz;
+                depth--;
+                fresh = true;
+                ended = depth <= 0;  // main.cpp:42 / main.cu:69
             } else {
-                // miss: main.cpp:36-38 (sky) or main.cu:63 (constant background)
-                float bg_r, bg_g, bg_b;
-                if (P.flags & RT_FLAG_SKY_GRADIENT) {
-                    const float t = 0.5f * (inv_len * dy + 1.0f);
-                    const float omt = 1.0f - t;
-                    bg_r = fmaf(t, 0.5f, omt), bg_g = fmaf(t, 0.7f, omt), bg_b = fmaf(t, 1.0f, omt);
-                } else {
-                    bg_r = P.background[0], bg_g = P.background[1], bg_b = P.background[2];
-                }
-                L_r = fmaf(beta_r, bg_r, L_r), L_g = fmaf(beta_g, bg_g, L_g), L_b = fmaf(beta_b, bg_b, L_b);
-                path_done = true;
-                if (COUNT) c_misses++;
+                ended = true;  // absorbed: main.cpp:32 / main.cu:55-58
             }
-            tick(3);
-            if (path_done && (RT_ABLATE & 2)) active = false;
-            if (path_done && !(RT_ABLATE & 2)) {  // res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
-                const unsigned long long fr = radiance_to_fixed(L_r), fg = radiance_to_fixed(L_g), fb = radiance_to_fixed(L_b);
-                if (slot >= 0) {
-                    unsigned long long *g = acc + (size_t)slot * 3;
-                    if (fr) atomicAdd(g + 0, fr);
-                    if (fg) atomicAdd(g + 1, fg);
-                    if (fb) atomicAdd(g + 2, fb);
-                } else {
-                    unsigned long long *a = c_acc + cur_p * 3;
-                    atomicAdd(a + 0, fr);
-                    atomicAdd(a + 1, fg);
-                    atomicAdd(a + 2, fb);
-                }
-                active = false;
-            }
-            tick(4);
         }
+        // ---- (6b) the camera ray of the paths that start (camera::get_ray, camera.h:32-39)
+        if (started) {
+                float offx = 0.0f, offy = 0.0f, offz = 0.0f;
+                // the camera's derived vectors come from the hot table (wave-uniform reads, used here only),
+                // not from kernel arguments that would sit in SGPRs for the whole launch
+                const float4 *cv = hot + P.off_cam;
+                const float4 c_org = cv[0];  // origin, lens_radius
+                if (P.flags & RT_FLAG_DEFOCUS_BLUR) {
+                    const float4 c_u = cv[4], c_v = cv[5];
+                    float rdx = c_org.w * sx, rdy = c_org.w * sy;
+                    offx = fmaf(c_u.x, rdx, c_v.x * rdy);
+                    offy = fmaf(c_u.y, rdx, c_v.y * rdy);
+                    offz = fmaf(c_u.z, rdx, c_v.z * rdy);
+                }
+                const float4 c_ll = cv[1], c_hor = cv[2], c_ver = cv[3];
+                dx = fmaf(v, c_ver.x, fmaf(u, c_hor.x, c_ll.x));
+                dy = fmaf(v, c_ver.y, fmaf(u, c_hor.y, c_ll.y));
+                dz = fmaf(v, c_ver.z, fmaf(u, c_hor.z, c_ll.z));
+                dx = (dx - c_org.x) - offx;
+                dy = (dy - c_org.y) - offy;
+                dz = (dz - c_org.z) - offz;
+                ox = c_org.x + offx;
+                oy = c_org.y + offy;
+                oz = c_org.z + offz;
+                beta_r = beta_g = beta_b = 1.0f;
+                L_r = L_g = L_b = 0.0f;
+                depth = P.max_depth;
+                active = true;
+                fresh = true;
+        }
+        // ---- (6c) what every new ray needs, however it came about
+        if (fresh) {
+            ra = dot3(dx, dy, dz, dx, dy, dz);
+            rinv_a = 1.0f / ra;
+        }
+        // Russian roulette before the next query (4_0_path_tracing.py:45-46; include/rtmi.h,
+        // rt_scene_set_russian_roulette): a path that does not survive keeps what it has collected (a new one:
+        // nothing, so there is nothing to add); a survivor's throughput is divided by p at once
+        if (P.rr_p > 0.0f) {
+            if (started) {
+                if (rng_next<COUNT>(rng) > P.rr_p) active = false;
+                beta_r = beta_g = beta_b = 1.0f / P.rr_p;
+            } else if (fresh && !ended) {
+                if (rng_next<COUNT>(rng) > P.rr_p) ended = true;
+                beta_r = beta_r / P.rr_p, beta_g = beta_g / P.rr_p, beta_b = beta_b / P.rr_p;
+            }
+        }
+        if (ended) active = false;  // no further query; its sample is added in step (3) of the next iteration
     }
 
     if (COUNT) {
