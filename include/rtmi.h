@@ -52,7 +52,9 @@ typedef enum rt_prim_type {
     RT_PRIM_XY_RECT = 1,  /* object.cuh:96-132  f = {x0,x1,y0,y1,k}          */
     RT_PRIM_XZ_RECT = 2,  /* object.cuh:134-164 f = {x0,x1,z0,z1,k}          */
     RT_PRIM_YZ_RECT = 3,  /* object.cuh:166-197 f = {y0,y1,z0,z1,k}          */
-    RT_PRIM_CYLINDER = 4  /* object.cuh:216-297 f = {radius,zmin,zmax}, m/m_inv */
+    RT_PRIM_CYLINDER = 4, /* object.cuh:216-297 f = {radius,zmin,zmax}, m/m_inv */
+    RT_PRIM_TRIANGLE = 5  /* taichi-version/hittable.py:38-71, 95-110: m[0..8] = v1, v2, v3; m[9..11] = the unit
+                             normal (v2-v1)x(v3-v1) / |..|; m_inv[0..5] = texture coordinates u1, u2, u3 (2 each) */
 } rt_prim_type;
 
 typedef enum rt_mat_type {
@@ -64,7 +66,9 @@ typedef enum rt_mat_type {
 
 typedef enum rt_tex_type {
     RT_TEX_SOLID = 0,   /* texture.cuh:14-31  c0                             */
-    RT_TEX_CHECKER = 1  /* texture.cuh:33-57  c0 = even, c1 = odd            */
+    RT_TEX_CHECKER = 1, /* texture.cuh:33-57  c0 = even, c1 = odd            */
+    RT_TEX_IMAGE = 2    /* taichi-version/material.py:137-144: texel lookup by the hit record's (u, v);
+                           c0 = {image index, rows, columns} as floats (exact: small integers) */
 } rt_tex_type;
 
 typedef struct rt_prim {
@@ -127,7 +131,9 @@ typedef struct rt_scene rt_scene; /* opaque; gpu-version/parser.hpp:16-32 `struc
  * background[3] max_depth samples_per_pixel width height
  * camera{lookfrom lookat vup vfov aperture} object.data[] material.data[]
  * texture.data[] [output_file].  Extensions: texture type "checker"
- * {even[3], odd[3]} (texture.cuh:33-57 has the class, the parser lacks it),
+ * {even[3], odd[3]} (texture.cuh:33-57 has the class, the parser lacks it), texture type "image" {"file": ppm} or
+ * {"rows", "cols", "data": [r, g, b, ...]}, object types "triangle" {v1, v2, v3, [u1, u2, u3]} and "mesh" {"file":
+ * obj, ["scale", "matrix"[9], "translate"]} (expanded into triangles when parsed),
  * optional top-level "sky_gradient": bool, "defocus_blur": bool (both default false: gpu-version renders a
  * constant background, main.cu:63, and has the lens sample disabled, camera.cuh:33-34) and
  * "russian_roulette": number in [0, 1].
@@ -180,6 +186,26 @@ int rt_scene_add_rect(rt_scene *s, int axis, float a0, float a1, float b0, float
 int rt_scene_add_cylinder(rt_scene *s, float radius, float zmin, float zmax, int material,
                           const float rot_axis[3], float rot_degrees, const float translate[3]);
 /* negative ids above = -rt_status */
+
+/* Image texture, taichi-version/material.py:96-110, 137-144 (the reference keeps one 100 x 100 image): `rgb` holds
+ * rows x cols texels, 3 bytes each (R, G, B), row-major.  value(u, v, p) = texel[int(frac(u) * rows)][int(frac(v) *
+ * cols)] / 255 (frac(x) = x - floor(x); an index that rounds up to rows / cols is clamped).  -> texture id.
+ * The hit record's u, v (sphere object.cuh:87-93, rects :113-114, cylinder :283-288, triangle hittable.py:233)
+ * are only evaluated for hits on materials with an image texture. */
+int rt_scene_add_image_texture(rt_scene *s, int rows, int cols, const uint8_t *rgb);
+/* the same from a binary or text PPM file (P6 / P3, maxval 255).  The reference's assets are JPEG / PNG files read
+ * through OpenCV; convert them once (`python -c "from PIL import Image; Image.open('a.png').convert('RGB').save('a.ppm')"`). */
+int rt_scene_add_image_texture_file(rt_scene *s, const char *path);
+/* rows / cols of image texture `texture` and, if out != NULL, its rows*cols*3 bytes; -rt_status on error */
+int rt_scene_get_image(const rt_scene *s, int texture, int *rows, int *cols, uint8_t *out, size_t cap);
+/* Triangle(v1, v2, v3, u1, u2, u3, material), taichi-version/hittable.py:95-110; uv pointers may be NULL (zeros) */
+int rt_scene_add_triangle(rt_scene *s, const float v1[3], const float v2[3], const float v3[3],
+                          const float uv1[2], const float uv2[2], const float uv3[2], int material);
+/* readobj + the placement loop of taichi-version/main.py:23-41, 110-118: "v x y z", "vt u v", "f a b c" lines (1-based;
+ * a face corner "a", "a/t" or "a/t/n"; without t the texture coordinate of corner a is vt[a], as in the reference);
+ * every vertex is mapped to scale * (M v) + translate (M = 3x3 row-major, NULL = identity).  -> triangles added */
+int rt_scene_add_obj(rt_scene *s, const char *path, int material, float scale, const float matrix[9],
+                     const float translate[3]);
 
 /* ---- animation (gpu-version/blue.py, blue2.py, dna.py: the frame harness) ----- */
 /* blue.py:16-19 / blue2.py:16-19: add `degrees` to rotate.angle of every cylinder that has a

@@ -46,6 +46,9 @@ struct error : std::runtime_error {
 struct mytexture {
     int type = RT_TEX_SOLID;
     color c0, c1;
+    // image texture (taichi-version/material.py:96-110, 137-144): rows x cols texels, R G B bytes
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> rgb;
 };
 inline std::shared_ptr<mytexture> solid_color(color c) {  // texture.cuh:18-19
     auto t = std::make_shared<mytexture>();
@@ -55,6 +58,12 @@ inline std::shared_ptr<mytexture> solid_color(color c) {  // texture.cuh:18-19
 inline std::shared_ptr<mytexture> checker_texture(color even, color odd) {  // texture.cuh:40-42
     auto t = std::make_shared<mytexture>();
     t->type = RT_TEX_CHECKER, t->c0 = even, t->c1 = odd;
+    return t;
+}
+
+inline std::shared_ptr<mytexture> image_texture(int rows, int cols, std::vector<uint8_t> rgb) {
+    auto t = std::make_shared<mytexture>();
+    t->type = RT_TEX_IMAGE, t->rows = rows, t->cols = cols, t->rgb = std::move(rgb);
     return t;
 }
 
@@ -94,6 +103,8 @@ struct hittable {
     int type = RT_PRIM_SPHERE;
     float f[6] = {0, 0, 0, 0, 0, 0};
     material_ptr mat;
+    // triangle only (taichi-version/hittable.py:95-110): corners and their texture coordinates
+    float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, uv[6] = {0, 0, 0, 0, 0, 0};
     // cylinder only: rotate (axis, radians) then translate, as cylinder::rotate/translate compose
     bool has_rotate = false, has_translate = false;
     vec3 axis{0, 0, 1}, offset;
@@ -126,6 +137,19 @@ inline hittable xz_rect(float x0, float x1, float z0, float z1, float k, materia
 }
 inline hittable yz_rect(float y0, float y1, float z0, float z1, float k, material_ptr m) {  // object.cuh:170-173
     return make_rect(RT_PRIM_YZ_RECT, y0, y1, z0, z1, k, std::move(m));
+}
+// Triangle(v1, v2, v3, u1, u2, u3, material), taichi-version/hittable.py:95-110 (u = texture coordinates, 2 each)
+inline hittable triangle(point3 v1, point3 v2, point3 v3, material_ptr m, const float *u1 = nullptr, const float *u2 = nullptr,
+                         const float *u3 = nullptr) {
+    hittable h;
+    h.type = RT_PRIM_TRIANGLE, h.mat = std::move(m);
+    const point3 *c[3] = {&v1, &v2, &v3};
+    const float *u[3] = {u1, u2, u3};
+    for (int k = 0; k < 3; ++k) {
+        h.v[3 * k] = c[k]->x(), h.v[3 * k + 1] = c[k]->y(), h.v[3 * k + 2] = c[k]->z();
+        if (u[k]) h.uv[2 * k] = u[k][0], h.uv[2 * k + 1] = u[k][1];
+    }
+    return h;
 }
 inline hittable cylinder(float radius, float zmin, float zmax, material_ptr m) {  // object.cuh:220-223
     hittable h;
@@ -172,6 +196,7 @@ public:
         int id;
         switch (h.type) {
         case RT_PRIM_SPHERE: id = rt_scene_add_sphere(s_, h.f, h.f[3], m); break;
+        case RT_PRIM_TRIANGLE: id = rt_scene_add_triangle(s_, h.v, h.v + 3, h.v + 6, h.uv, h.uv + 2, h.uv + 4, m); break;
         case RT_PRIM_CYLINDER: {
             const float deg = h.radians * 180.0f / 3.14159265358979323846f;
             id = rt_scene_add_cylinder(s_, h.f[0], h.f[1], h.f[2], m, h.has_rotate ? h.axis.e : nullptr, deg,
@@ -182,6 +207,13 @@ public:
         }
         if (id < 0) throw error(-id, "add");
         return id;
+    }
+    // readobj + placement (taichi-version/main.py:23-41, 110-118): triangles added
+    int add_obj(const std::string &path, const material_ptr &m, float scale = 1.0f, const float *matrix9 = nullptr,
+                const float *translate3 = nullptr) {
+        int n = rt_scene_add_obj(s_, path.c_str(), material_id(m), scale, matrix9, translate3);
+        if (n < 0) throw error(-n, "add_obj");
+        return n;
     }
     void override_size(int w, int h, int spp, int depth) { check(rt_scene_override(s_, w, h, spp, depth), "override"); }
 
@@ -237,7 +269,9 @@ private:
     int texture_id(const std::shared_ptr<mytexture> &t) {
         for (auto &kv : texs_)
             if (kv.first == t) return kv.second;
-        int id = t->type == RT_TEX_CHECKER ? rt_scene_add_checker(s_, t->c0.e, t->c1.e) : rt_scene_add_solid_color(s_, t->c0.e);
+        int id = t->type == RT_TEX_CHECKER ? rt_scene_add_checker(s_, t->c0.e, t->c1.e)
+                 : t->type == RT_TEX_IMAGE ? rt_scene_add_image_texture(s_, t->rows, t->cols, t->rgb.data())
+                                           : rt_scene_add_solid_color(s_, t->c0.e);
         if (id < 0) throw error(-id, "texture");
         texs_.emplace_back(t, id);
         return id;

@@ -189,6 +189,10 @@ typedef struct hit_record {
     int material;
     float t;
     int front_face;
+    /* rec.u, rec.v (gpu/hittable.cuh:12-13) are evaluated where a texture reads them (hit_uv below): only image
+     * textures do, and get_sphere_uv's acos / atan2 per candidate hit would dominate sphere::hit.  What they are
+     * computed from: */
+    const struct rto_prim *prim;
 } hit_record;
 
 /* hit_record::set_face_normal, cpu/hittable.h:17-20 */
@@ -221,6 +225,7 @@ static int sphere_hit(const rto_prim *sp, const ray_t *r, float t_min, float t_m
     vec3 normal = vscale(1.0f / radius, vsub(rec->p, center)); /* (p - c) / r */
     set_face_normal(rec, r, normal);
     rec->material = sp->material;
+    rec->prim = sp;
     return 1;
 }
 
@@ -247,6 +252,7 @@ static int rect_hit(const rto_prim *rc, const ray_t *r, float t_min, float t_max
     rec->normal = rec->front_face ? outward : vneg(outward);
     rec->material = rc->material;
     rec->p = ray_at(r, t);
+    rec->prim = rc;
     return 1;
 }
 
@@ -309,7 +315,127 @@ static int cylinder_hit(const rto_prim *cy, const ray_t *r, float t_min, float t
     set_face_normal(rec, r, wn);
     rec->material = cy->material;
     rec->t = t;
+    rec->prim = cy;
     return 1;
+}
+
+/* ------------------------------------------------------------------ triangle
+ * hit_triangle, taichi-version/hittable.py:38-71.  cross(a, b) with one fused multiply-add per component. */
+static inline vec3 cross(vec3 a, vec3 b) {
+    return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+/* the plane point r_interact and the ray parameter (hittable.py:44-52, 61) */
+static int triangle_plane(const rto_prim *tr, const ray_t *r, vec3 *ri, float *root) {
+    vec3 v1 = v3(tr->m[0], tr->m[1], tr->m[2]);
+    vec3 n = v3(tr->m[9], tr->m[10], tr->m[11]);
+    vec3 oc = vsub(r->orig, v1);
+    float ocn = dot(oc, n);
+    if (ocn < 0.0f) n = vneg(n), ocn = -ocn; /* n = -n: oc.dot(n) changes sign exactly */
+    float a = sqrtf(r->a);                   /* ray_direction.norm() */
+    float theta = dot(r->dir, n) / a;
+    if (!(theta < 0.0f)) return 0;
+    *ri = v3(r->orig.x - ((r->dir.x / a) * ocn) / theta, r->orig.y - ((r->dir.y / a) * ocn) / theta,
+             r->orig.z - ((r->dir.z / a) * ocn) / theta);
+    *root = ((-ocn) / theta) / a;
+    return 1;
+}
+
+static int triangle_hit(const rto_prim *tr, const ray_t *r, float t_min, float t_max, hit_record *rec) {
+    vec3 v1 = v3(tr->m[0], tr->m[1], tr->m[2]), v2 = v3(tr->m[3], tr->m[4], tr->m[5]), v3_ = v3(tr->m[6], tr->m[7], tr->m[8]);
+    vec3 ri;
+    float root;
+    if (!triangle_plane(tr, r, &ri, &root)) return 0;
+    if (root < t_min || root > t_max) return 0;
+    vec3 e21 = vsub(v2, v1), e31 = vsub(v3_, v1), e32 = vsub(v3_, v2), e12 = vneg(e21);
+    vec3 a1 = vsub(ri, v1), a2 = vsub(ri, v2);
+    float n1 = dot(cross(a1, e21), cross(e31, e21));
+    float n2 = dot(cross(a2, e12), cross(e32, e12));
+    float n3 = dot(cross(a1, e31), cross(e21, e31));
+    float n4 = dot(cross(a2, e32), cross(e12, e32));
+    if (!(n1 > 0.0f && n2 > 0.0f && n3 > 0.0f && n4 > 0.0f)) return 0;
+    rec->t = root;
+    rec->p = ray_at(r, root);
+    set_face_normal(rec, r, v3(tr->m[9], tr->m[10], tr->m[11])); /* hittable.py:254-259 */
+    rec->material = tr->material;
+    rec->prim = tr;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ texture coordinates
+ * atan2 / acos with a fixed fp32 operation sequence (the HIP kernel's csrc/rt_trig.h, operation for operation):
+ * Cephes atanf's reduction and polynomial. */
+static float atan_unit(float a) {
+    float y0 = 0.0f, t = a;
+    if (a > 0.4142135679721832275390625f) {
+        y0 = 0.785398185253143310546875f;
+        t = (a - 1.0f) / (a + 1.0f);
+    }
+    float z = t * t;
+    float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    return y0 + fmaf(p * z, t, t);
+}
+float rto_atan2f(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float r = 0.0f;
+    if (mx > 0.0f) r = atan_unit(mn / mx);
+    if (ay > ax) r = 1.57079637050628662109375f - r;
+    if (x < 0.0f) r = 3.1415927410125732421875f - r;
+    return y < 0.0f ? -r : r;
+}
+float rto_acosf(float c) {
+    float s = sqrtf(fmaxf((1.0f - c) * (1.0f + c), 0.0f));
+    return rto_atan2f(s, c);
+}
+
+/* rec.u, rec.v of the accepted hit: sphere gpu/object.cuh:87-93 (get_sphere_uv of the OUTWARD normal), rects
+ * :113-114 / 150-151 / 183-184, cylinder :283-288 (object space), triangle taichi hittable.py:54-58, 233 */
+static void hit_uv(const hit_record *rec, const ray_t *r, float *u, float *v) {
+    const rto_prim *p = rec->prim;
+    const float pi = 3.1415927410125732421875f;
+    switch (p->type) {
+    case 0: {
+        vec3 on = rec->front_face ? rec->normal : vneg(rec->normal);
+        float theta = rto_acosf(-on.y);
+        float phi = rto_atan2f(-on.z, on.x) + pi;
+        *u = phi / 6.283185482025146484375f;
+        *v = theta / pi;
+        break;
+    }
+    case 1:
+    case 2:
+    case 3: {
+        float pa = p->type == 3 ? rec->p.y : rec->p.x, pb = p->type == 1 ? rec->p.y : rec->p.z;
+        *u = (pa - p->f[0]) / (p->f[1] - p->f[0]);
+        *v = (pb - p->f[2]) / (p->f[3] - p->f[2]);
+        break;
+    }
+    case 4: {
+        vec3 oo = xf_point(p->m_inv, r->orig), od = xf_vec(p->m_inv, r->dir);
+        vec3 op = vfma(rec->t, od, oo);
+        float phi = rto_atan2f(op.y, op.x) + 6.283185482025146484375f;
+        *u = phi / 12.56637096405029296875f;
+        *v = (op.z - p->f[1]) / (p->f[2] - p->f[1]);
+        break;
+    }
+    default: {
+        vec3 v1 = v3(p->m[0], p->m[1], p->m[2]), v2 = v3(p->m[3], p->m[4], p->m[5]), v3_ = v3(p->m[6], p->m[7], p->m[8]);
+        vec3 ri;
+        float root;
+        triangle_plane(p, r, &ri, &root);
+        vec3 a1 = vsub(ri, v1), a2 = vsub(ri, v2), a3 = vsub(ri, v3_);
+        float w1 = sqrtf(length_squared(cross(a1, a2))) / sqrtf(length_squared(cross(vsub(v3_, v1), vsub(v3_, v2))));
+        float w2 = sqrtf(length_squared(cross(a1, a3))) / sqrtf(length_squared(cross(vsub(v2, v1), vsub(v2, v3_))));
+        float w3 = sqrtf(length_squared(cross(a3, a2))) / sqrtf(length_squared(cross(vsub(v1, v3_), vsub(v1, v2))));
+        const float *t = p->m_inv; /* u1, u2, u3 */
+        *u = fmaf(t[4], w3, fmaf(t[2], w2, t[0] * w1));
+        *v = fmaf(t[5], w3, fmaf(t[3], w2, t[1] * w1));
+        break;
+    }
+    }
 }
 
 /* hittable_list::hit, cpu/hittable_list.h:23-37 (= gpu/object.cuh:23-37) */
@@ -326,7 +452,8 @@ static int world_hit(const rto_scene *s, const ray_t *r, float t_min, float t_ma
         case 1:
         case 2:
         case 3: h = rect_hit(p, r, t_min, closest_so_far, &temp_rec); break;
-        default: h = cylinder_hit(p, r, t_min, closest_so_far, &temp_rec); break;
+        case 4: h = cylinder_hit(p, r, t_min, closest_so_far, &temp_rec); break;
+        default: h = triangle_hit(p, r, t_min, closest_so_far, &temp_rec); break;
         }
         if (h) {
             hit_anything = 1;
@@ -345,10 +472,21 @@ static int world_hit(const rto_scene *s, const ray_t *r, float t_min, float t_ma
  * solid_color::value cpu/texture.hpp:11-26; checker_texture::value :28-49.
  * sin(t) < 0  <=>  floor(t/pi) odd (t != 0), so the sign of the triple product is
  * the parity of the three floors; a zero factor makes the product 0 -> "even". */
-static vec3 texture_value(const rto_scene *s, int tex, vec3 p) {
+static vec3 texture_value(const rto_scene *s, int tex, const hit_record *rec, const ray_t *r) {
     const rto_texture *t = &s->texs[tex];
+    const vec3 p = rec->p;
     vec3 c0 = v3(t->c0[0], t->c0[1], t->c0[2]);
     if (t->type == 0) return c0;
+    if (t->type == 2) { /* taichi-version/material.py:137-144: texel[int(frac(u) rows)][int(frac(v) cols)] / 255 */
+        const rto_image *im = &s->images[(int)t->c0[0]];
+        float u, v;
+        hit_uv(rec, r, &u, &v);
+        int x = (int)((u - floorf(u)) * (float)im->rows), y = (int)((v - floorf(v)) * (float)im->cols);
+        if (x > im->rows - 1) x = im->rows - 1;
+        if (y > im->cols - 1) y = im->cols - 1;
+        const uint8_t *px = im->rgb + ((size_t)x * im->cols + y) * 3;
+        return v3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    }
     const float inv_pi = 0.318309886183790671538f;
     float tx = 10.0f * p.x, ty = 10.0f * p.y, tz = 10.0f * p.z;
     int kx = (int)floorf(tx * inv_pi), ky = (int)floorf(ty * inv_pi), kz = (int)floorf(tz * inv_pi);
@@ -360,12 +498,12 @@ static vec3 texture_value(const rto_scene *s, int tex, vec3 p) {
 /* ------------------------------------------------------------------ materials */
 
 /* lambertian::scatter, cpu/material.h:25-35 */
-static int lambertian_scatter(const rto_scene *s, const rto_material *m, const hit_record *rec,
+static int lambertian_scatter(const rto_scene *s, const rto_material *m, const ray_t *r_in, const hit_record *rec,
                               vec3 *attenuation, ray_t *scattered, rng_t *g) {
     vec3 dir = vadd(rec->normal, random_unit_vector(g));
     if (near_zero(dir)) dir = rec->normal;
     *scattered = make_ray(rec->p, dir);
-    *attenuation = texture_value(s, m->texture, rec->p);
+    *attenuation = texture_value(s, m->texture, rec, r_in);
     return 1;
 }
 
@@ -513,11 +651,11 @@ static vec3 ray_color(const rto_scene *s, ray_t now, int depth, rng_t *g, rto_co
                 cnt->scatter[m->type]++;
             }
             switch (m->type) {
-            case 0: did_scatter = lambertian_scatter(s, m, &rec, &attenuation, &scattered, g); break;
+            case 0: did_scatter = lambertian_scatter(s, m, &now, &rec, &attenuation, &scattered, g); break;
             case 1: did_scatter = metal_scatter(m, &now, &rec, &attenuation, &scattered, g); break;
             case 2: did_scatter = dielectric_scatter(m, &now, &rec, &attenuation, &scattered, g); break;
             default: { /* diffuse_light, gpu/material.cuh:161-182: emits, never scatters */
-                vec3 e = texture_value(s, m->texture, rec.p);
+                vec3 e = texture_value(s, m->texture, &rec, &now);
                 L = v3(fmaf(e.x, beta.x, L.x), fmaf(e.y, beta.y, L.y), fmaf(e.z, beta.z, L.z));
                 did_scatter = 0;
                 break;
@@ -572,6 +710,17 @@ int rto_trace_sample(const rto_scene *s, uint64_t seed, int x, int y, int sample
     rto_sample(s, seed, x, y, sample, rgb, 0);
     g_trace = 0;
     return g_trace_n;
+}
+
+int rto_hit_uv(const rto_scene *s, const float o[3], const float d[3], float uv[2], float *t, int *prim) {
+    ray_t r = make_ray(v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]));
+    hit_record rec;
+    memset(&rec, 0, sizeof rec);
+    if (!world_hit(s, &r, 0.001f, INFINITY, &rec, 0)) return 0;
+    hit_uv(&rec, &r, &uv[0], &uv[1]);
+    if (t) *t = rec.t;
+    if (prim) *prim = (int)(rec.prim - s->prims);
+    return 1;
 }
 
 static void counts_add(rto_counts *a, const rto_counts *b) {

@@ -20,7 +20,8 @@ extern "C" {
  * rt_texture so a test can pass the product's exported tables straight in
  * (tests assert the sizes match). */
 typedef struct rto_prim {
-    int32_t type;     /* 0 sphere, 1 xy_rect, 2 xz_rect, 3 yz_rect, 4 cylinder */
+    int32_t type;     /* 0 sphere, 1 xy_rect, 2 xz_rect, 3 yz_rect, 4 cylinder, 5 triangle (m = v1, v2, v3, unit
+                         normal; m_inv[0..5] = texture coordinates of the three corners) */
     int32_t material;
     float f[6];
     float m[12];
@@ -36,10 +37,15 @@ typedef struct rto_material {
 } rto_material;
 
 typedef struct rto_texture {
-    int32_t type;     /* 0 solid, 1 checker (c0 even, c1 odd) */
+    int32_t type;     /* 0 solid, 1 checker (c0 even, c1 odd), 2 image (c0 = {image index, rows, cols}) */
     float c0[3];
     float c1[3];
 } rto_texture;
+
+typedef struct rto_image { /* taichi-version/material.py:96-110: rows x cols texels, R G B bytes */
+    int32_t rows, cols;
+    const uint8_t *rgb;
+} rto_image;
 
 typedef struct rto_camera_params {
     double lookfrom[3], lookat[3], vup[3];
@@ -67,6 +73,8 @@ typedef struct rto_scene {
     const rto_texture *texs;
     int32_t num_texs;
     float rr_p; /* Russian-roulette survival probability per bounce, 0 = off */
+    const rto_image *images; /* pixels of the image textures */
+    int32_t num_images;
 } rto_scene;
 
 typedef struct rto_counts {
@@ -95,6 +103,13 @@ int rto_render_rect(const rto_scene *s, uint64_t seed, int x0, int x1, int y0, i
 /* bench.py's CPU-baseline timing of this restatement on a systematic row sample (seconds) */
 double rto_time_sample(const rto_scene *s, uint64_t seed, int y0, int y1, int period, int band, int spp,
                        int threads, double *checksum, long long *pixels);
+
+/* the fixed-sequence fp32 atan2 / acos behind the texture coordinates (known-answer tests) */
+float rto_atan2f(float y, float x);
+float rto_acosf(float c);
+/* (u, v) of the hit record and the image-texture value there for the closest hit of the ray (o, d); returns 0 on a miss
+ * (known-answer tests of the texture coordinates: gpu/object.cuh:87-93, 113-114, 283-288, taichi hittable.py:54-58, 233) */
+int rto_hit_uv(const rto_scene *s, const float o[3], const float d[3], float uv[2], float *t, int *prim);
 
 void rto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void rto_sample_stream(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t *out, int n);

@@ -38,9 +38,9 @@ _lib = C.CDLL(_LIB_PATH)
 RT_OK = 0
 FLAG_SKY_GRADIENT = 1
 FLAG_DEFOCUS_BLUR = 2
-PRIM_SPHERE, PRIM_XY_RECT, PRIM_XZ_RECT, PRIM_YZ_RECT, PRIM_CYLINDER = range(5)
+PRIM_SPHERE, PRIM_XY_RECT, PRIM_XZ_RECT, PRIM_YZ_RECT, PRIM_CYLINDER, PRIM_TRIANGLE = range(6)
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = range(4)
-TEX_SOLID, TEX_CHECKER = range(2)
+TEX_SOLID, TEX_CHECKER, TEX_IMAGE = range(3)
 
 # numpy views of the table records (layouts of include/rtmi.h)
 PRIM_DTYPE = np.dtype(
@@ -149,6 +149,11 @@ _sig("rt_scene_add_diffuse_light", C.c_int, _p, C.c_int)
 _sig("rt_scene_add_sphere", C.c_int, _p, _f3, C.c_float, C.c_int)
 _sig("rt_scene_add_rect", C.c_int, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int)
 _sig("rt_scene_add_cylinder", C.c_int, _p, C.c_float, C.c_float, C.c_float, C.c_int, _f3, C.c_float, _f3)
+_sig("rt_scene_add_image_texture", C.c_int, _p, C.c_int, C.c_int, _p)
+_sig("rt_scene_add_image_texture_file", C.c_int, _p, C.c_char_p)
+_sig("rt_scene_get_image", C.c_int, _p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _p, C.c_size_t)
+_sig("rt_scene_add_triangle", C.c_int, _p, _f3, _f3, _f3, _f3, _f3, _f3, C.c_int)
+_sig("rt_scene_add_obj", C.c_int, _p, C.c_char_p, C.c_int, C.c_float, _f3, _f3)
 _sig("rt_scene_override", C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int)
 _sig("rt_scene_rotate_cylinders", C.c_int, _p, C.c_double)
 _sig("rt_scene_set_output_file", C.c_int, _p, C.c_char_p)
@@ -185,6 +190,8 @@ C_SYMBOLS = [
     "rt_scene_new", "rt_scene_set_background", "rt_scene_set_camera", "rt_scene_add_solid_color",
     "rt_scene_add_checker", "rt_scene_add_lambertian", "rt_scene_add_metal", "rt_scene_add_dielectric",
     "rt_scene_add_diffuse_light", "rt_scene_add_sphere", "rt_scene_add_rect", "rt_scene_add_cylinder",
+    "rt_scene_add_image_texture", "rt_scene_add_image_texture_file", "rt_scene_get_image", "rt_scene_add_triangle",
+    "rt_scene_add_obj",
     "rt_scene_override", "rt_scene_get_info", "rt_scene_get_camera", "rt_scene_get_prims",
     "rt_scene_get_materials", "rt_scene_get_textures", "rt_shard_rows", "rt_shard_global_row",
     "rt_render_hip_device", "rt_render_hip", "rt_render_hip_tiles", "rt_tiles_shutdown", "rt_shard_place_rows_device", "rt_render_hip_count", "rt_render_hip_accumulate", "rt_scene_set_russian_roulette",
@@ -270,6 +277,36 @@ class Scene:
 
     def checker_texture(self, even, odd) -> int:
         return _check_id(_lib.rt_scene_add_checker(self._h, _v3(even), _v3(odd)), "checker_texture")
+
+    def image_texture(self, pixels) -> int:
+        """Image texture (taichi-version/material.py:137-144) from a (rows, cols, 3) uint8 array or a PPM file."""
+        if isinstance(pixels, (str, bytes, os.PathLike)):
+            return _check_id(_lib.rt_scene_add_image_texture_file(self._h, os.fsencode(pixels)), "image_texture")
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        if px.ndim != 3 or px.shape[2] != 3:
+            raise ValueError("image texture pixels must have shape (rows, cols, 3)")
+        return _check_id(_lib.rt_scene_add_image_texture(self._h, px.shape[0], px.shape[1], px.ctypes.data_as(C.c_void_p)),
+                         "image_texture")
+
+    def get_image(self, texture: int) -> np.ndarray:
+        rows, cols = C.c_int(), C.c_int()
+        _check_id(_lib.rt_scene_get_image(self._h, texture, C.byref(rows), C.byref(cols), None, 0), "rt_scene_get_image")
+        out = np.empty((rows.value, cols.value, 3), dtype=np.uint8)
+        _check_id(_lib.rt_scene_get_image(self._h, texture, None, None, out.ctypes.data_as(C.c_void_p), out.nbytes),
+                  "rt_scene_get_image")
+        return out
+
+    def triangle(self, v1, v2, v3, material, u1=(0, 0), u2=(0, 0), u3=(0, 0)) -> int:
+        """Triangle(v1, v2, v3, u1, u2, u3, material), taichi-version/hittable.py:95-110."""
+        uv = [(C.c_float * 3)(float(u[0]), float(u[1]), 0.0) for u in (u1, u2, u3)]
+        return _check_id(_lib.rt_scene_add_triangle(self._h, _v3(v1), _v3(v2), _v3(v3), uv[0], uv[1], uv[2], material),
+                         "triangle")
+
+    def add_obj(self, path, material, scale=1.0, matrix=None, translate=None) -> int:
+        """readobj + placement, taichi-version/main.py:23-41, 110-118; returns the number of triangles added."""
+        m = (C.c_float * 9)(*[float(x) for x in np.asarray(matrix, dtype=np.float64).reshape(9)]) if matrix is not None else None
+        t = _v3(translate) if translate is not None else None
+        return _check_id(_lib.rt_scene_add_obj(self._h, os.fsencode(path), material, scale, m, t), "add_obj")
 
     def lambertian(self, texture_or_color) -> int:
         tex = texture_or_color if isinstance(texture_or_color, int) else self.solid_color(texture_or_color)

@@ -100,7 +100,16 @@ rt_scene *rt_scene_load_json(const char *path) {
     std::stringstream ss;
     ss << f.rdbuf();
     std::string text = ss.str();
-    return rt_scene_parse_json(text.data(), text.size());
+    rt_scene *s = new (std::nothrow) rt_scene();
+    if (!s) {
+        set_error("out of memory");
+        return nullptr;
+    }
+    // "file" entries of image textures and meshes are relative to the scene file
+    std::string dir(path);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    return finish(s, scene_from_json(text.data(), text.size(), s->s, dir.c_str()));
 }
 
 rt_scene *rt_scene_rtiow(uint32_t seed, int width, int height, int spp, int max_depth) {
@@ -251,6 +260,61 @@ int rt_scene_add_sphere(rt_scene *s, const float center[3], float radius, int ma
     s->s.xforms.emplace_back();
     s->s.touch();
     return (int)s->s.prims.size() - 1;
+}
+
+int rt_scene_add_image_texture(rt_scene *s, int rows, int cols, const uint8_t *rgb) {
+    if (bad_scene(s, "rt_scene_add_image_texture")) return -RT_ERR_ARG;
+    return add_image_texture(s->s, rows, cols, rgb, "");
+}
+
+int rt_scene_add_image_texture_file(rt_scene *s, const char *path) {
+    if (bad_scene(s, "rt_scene_add_image_texture_file")) return -RT_ERR_ARG;
+    if (!path) {
+        set_error("rt_scene_add_image_texture_file: null path");
+        return -RT_ERR_ARG;
+    }
+    return add_image_texture_file(s->s, path);
+}
+
+int rt_scene_get_image(const rt_scene *s, int texture, int *rows, int *cols, uint8_t *out, size_t cap) {
+    if (bad_scene(s, "rt_scene_get_image")) return -RT_ERR_ARG;
+    if (texture < 0 || texture >= (int)s->s.texs.size() || s->s.texs[texture].type != RT_TEX_IMAGE) {
+        set_error("texture %d is not an image texture", texture);
+        return -RT_ERR_ARG;
+    }
+    const SceneImage &im = s->s.images[(size_t)s->s.texs[texture].c0[0]];
+    if (rows) *rows = im.rows;
+    if (cols) *cols = im.cols;
+    if (out) {
+        if (cap < im.rgb.size()) {
+            set_error("rt_scene_get_image: buffer of %zu bytes, image needs %zu", cap, im.rgb.size());
+            return -RT_ERR_ARG;
+        }
+        memcpy(out, im.rgb.data(), im.rgb.size());
+    }
+    return RT_OK;
+}
+
+int rt_scene_add_triangle(rt_scene *s, const float v1[3], const float v2[3], const float v3[3], const float uv1[2],
+                          const float uv2[2], const float uv3[2], int material) {
+    if (bad_scene(s, "rt_scene_add_triangle")) return -RT_ERR_ARG;
+    if (!v1 || !v2 || !v3) {
+        set_error("triangle vertex is null");
+        return -RT_ERR_ARG;
+    }
+    if (bad_material(s, material)) return -RT_ERR_SCENE;
+    return add_triangle(s->s, v1, v2, v3, uv1, uv2, uv3, material);
+}
+
+int rt_scene_add_obj(rt_scene *s, const char *path, int material, float scale, const float matrix[9],
+                     const float translate[3]) {
+    if (bad_scene(s, "rt_scene_add_obj")) return -RT_ERR_ARG;
+    if (!path) {
+        set_error("rt_scene_add_obj: null path");
+        return -RT_ERR_ARG;
+    }
+    if (bad_material(s, material)) return -RT_ERR_SCENE;
+    return add_obj(s->s, path, material, scale, matrix, translate);
 }
 
 int rt_scene_add_rect(rt_scene *s, int axis, float a0, float a1, float b0, float b1, float k, int material) {

@@ -8,11 +8,15 @@
 //     rect    [nr]  2 x float4   {a0, a1, b0, b1} {k, axis(bits), 0, 0}
 //     cyl     [nc]  4 x float4   m_inv rows 0..2, {radius^2, zmin, zmax, 0}
 //     cbox    [nc]  2 x float4   world-space bounding box of each cylinder (culling variant)
+//     tri     [nt]  3 x float4   {v1.xyz, n.x} {v2.xyz, n.y} {v3.xyz, n.z}   (n = unit normal, hittable.py:104)
+//     tbox    [nt]  2 x float4   bounding box of each triangle (culling variant)
 //   COLD part (stays in global memory / L2; read once per bounce by the winning lane)
 //     sphere  [ns]  1 x float4   {1/r, material(bits), list index(bits), 0}
 //     rect    [nr]  1 x float4   {material(bits), list index(bits), 0, 0}
 //     cyl     [nc]  4 x float4   m rows 0..2, {material(bits), list index(bits), 0, 0}
+//     tri     [nt]  2 x float4   {material(bits), list index(bits), u1.x, u1.y} {u2.x, u2.y, u3.x, u3.y}
 //     mat     [nm]  3 x float4   {kind(bits), p0, p1, p2} {c0.xyz, p3} {c1.xyz, 0}
+//     image   texels of the image textures, one 32-bit word each (r | g << 8 | b << 16), row-major
 //
 // Primitives are grouped by type (spheres, rects, cylinders), each group in list
 // order; the original list index is kept for the reference's tie rule (a later
@@ -41,10 +45,12 @@ namespace rtmi {
 enum MatKind : int32_t {
     MK_LAMBERT_SOLID = 0,    // c0 = albedo
     MK_LAMBERT_CHECKER = 1,  // c0 = even, c1 = odd
-    MK_METAL = 2,            // c0 = albedo, p0 = fuzz
-    MK_DIELECTRIC = 3,       // p0 = ir, p1 = 1/ir, p2 = r0(1/ir), p3 = r0(ir)
-    MK_LIGHT_SOLID = 4,      // c0 = emission
-    MK_LIGHT_CHECKER = 5     // c0 = even, c1 = odd
+    MK_LAMBERT_IMAGE = 2,    // c0 = {texel word offset (bits), rows (bits), cols (bits)}: image texture
+    MK_METAL = 3,            // c0 = albedo, p0 = fuzz
+    MK_DIELECTRIC = 4,       // p0 = ir, p1 = 1/ir, p2 = r0(1/ir), p3 = r0(ir)
+    MK_LIGHT_SOLID = 5,      // c0 = emission
+    MK_LIGHT_CHECKER = 6,    // c0 = even, c1 = odd
+    MK_LIGHT_IMAGE = 7       // as MK_LAMBERT_IMAGE
 };
 
 // Per-launch values the kernel needs only when a wave fetches or flushes a work item.  They live in global
@@ -73,6 +79,8 @@ struct RenderParams {
     uint32_t seed_lo, seed_hi;
     // scene image
     int32_t ns, nr, nc, nm;
+    int32_t nt;              // triangles (grouped ids ns + nr + nc ...)
+    int32_t off_tri_hot, off_tbox, off_tri_cold;
     int32_t ns_pad;          // sphere slots incl. never-hit padding (= ns)
     int32_t np;              // leading slots that are always tested (big spheres), multiple of 8
     int32_t ncl;             // clusters of 8 slots after the prefix, each with a bounding box

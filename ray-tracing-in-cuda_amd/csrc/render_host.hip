@@ -23,8 +23,9 @@
 namespace rtmi {
 
 void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
-                   DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant);
-int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster);
+                   DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant, bool ext);
+int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster, bool ext);
+bool variant_has_ext(unsigned variant);
 void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream);
 void launch_item_params(unsigned int *queue, const ItemParams &ip, hipStream_t stream);
 int set_max_dynamic_lds(size_t bytes);
@@ -80,11 +81,12 @@ static inline float bits(int32_t v) {
 
 // ---- scene tables -> device image ------------------------------------------------
 static void pack_scene(const Scene &s, DeviceSceneCache &c) {
-    std::vector<int> sph, rec, cyl;
+    std::vector<int> sph, rec, cyl, tri;
     for (size_t i = 0; i < s.prims.size(); ++i) {
         switch (s.prims[i].type) {
         case RT_PRIM_SPHERE: sph.push_back((int)i); break;
         case RT_PRIM_CYLINDER: cyl.push_back((int)i); break;
+        case RT_PRIM_TRIANGLE: tri.push_back((int)i); break;
         default: rec.push_back((int)i); break;
         }
     }
@@ -167,6 +169,7 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     RenderParams &L = c.layout;
     memset(&L, 0, sizeof L);
     L.ns = ns_slots, L.nr = (int)rec.size(), L.nc = (int)cyl.size(), L.nm = (int)s.mats.size();
+    L.nt = (int)tri.size();
     L.ns_pad = ns_slots;
     L.np = np_slots;
     L.ncl = n_clusters;
@@ -188,6 +191,10 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     off += 4 * L.nc;
     L.off_cbox = off;
     off += 2 * L.nc;
+    L.off_tri_hot = off;
+    off += 3 * L.nt;
+    L.off_tbox = off;
+    off += 2 * L.nt;
     L.off_cam = off;  // camera::camera's derived vectors (camera.h:9-31): read once per new sample
     off += 6;
     // Range tables (candidate clusters of a ray segment without testing every box): per window of 64 clusters and
@@ -222,8 +229,16 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     off += L.nr;
     L.off_cyl_cold = off;
     off += 4 * L.nc;
+    L.off_tri_cold = off;
+    off += 2 * L.nt;
     L.off_mat = off;
     off += 3 * L.nm;
+    // texels of the image textures: one 32-bit word each, every image starts on a float4 record
+    std::vector<int> image_word(s.images.size(), 0);
+    for (size_t k = 0; k < s.images.size(); ++k) {
+        image_word[k] = off * 4;
+        off += (int)(((size_t)s.images[k].rows * s.images[k].cols + 3) / 4);
+    }
     c.image.assign((size_t)(off > 0 ? off : 1) * 4, 0.0f);
     float *I = c.image.data();
     auto rec4 = [&](int idx) { return I + (size_t)idx * 4; };
@@ -287,8 +302,20 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
             extent = std::max(extent, (float)std::max(std::fabs(lo), std::fabs(hi)));
         }
     }
+    for (int k = 0; k < L.nt; ++k) {
+        const rt_prim &p = s.prims[tri[k]];
+        for (int c = 0; c < 9; ++c) extent = std::max(extent, std::fabs(p.m[c]));
+    }
     L.cull_extent1 = extent + 1.0f;
     const float inflate = 1e-5f * (extent + 1.0f);
+    for (int k = 0; k < L.nt; ++k) {
+        const rt_prim &p = s.prims[tri[k]];
+        float *b = rec4(L.off_tbox + 2 * k);
+        for (int a = 0; a < 3; ++a) {
+            b[a] = std::min(p.m[a], std::min(p.m[3 + a], p.m[6 + a])) - inflate;
+            b[4 + a] = std::max(p.m[a], std::max(p.m[3 + a], p.m[6 + a])) + inflate;
+        }
+    }
     for (int k = 0; k < L.nc; ++k) {
         float *b = rec4(L.off_cbox + 2 * k);
         for (int a = 0; a < 3; ++a) b[a] = cyl_box[k * 6 + a] - inflate, b[4 + a] = cyl_box[k * 6 + 3 + a] + inflate;
@@ -383,6 +410,24 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         cd[12] = bits(p.material);
         cd[13] = bits(cyl[k]);
     }
+    for (int k = 0; k < L.nt; ++k) {
+        const rt_prim &p = s.prims[tri[k]];
+        float *h = rec4(L.off_tri_hot + 3 * k);
+        for (int c = 0; c < 3; ++c) {
+            h[4 * c] = p.m[3 * c], h[4 * c + 1] = p.m[3 * c + 1], h[4 * c + 2] = p.m[3 * c + 2];
+            h[4 * c + 3] = p.m[9 + c];
+        }
+        float *cd = rec4(L.off_tri_cold + 2 * k);
+        cd[0] = bits(p.material), cd[1] = bits(tri[k]);
+        cd[2] = p.m_inv[0], cd[3] = p.m_inv[1];
+        cd[4] = p.m_inv[2], cd[5] = p.m_inv[3], cd[6] = p.m_inv[4], cd[7] = p.m_inv[5];
+    }
+    for (size_t k = 0; k < s.images.size(); ++k) {
+        const SceneImage &im = s.images[k];
+        uint32_t *w = reinterpret_cast<uint32_t *>(I) + image_word[k];
+        for (size_t t = 0; t < (size_t)im.rows * im.cols; ++t)
+            w[t] = (uint32_t)im.rgb[3 * t] | ((uint32_t)im.rgb[3 * t + 1] << 8) | ((uint32_t)im.rgb[3 * t + 2] << 16);
+    }
     for (int k = 0; k < L.nm; ++k) {
         const rt_material &m = s.mats[k];
         float *q = rec4(L.off_mat + 3 * k);
@@ -394,7 +439,11 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
             bool light = m.type == RT_MAT_DIFFUSE_LIGHT;
             bool checker = t && t->type == RT_TEX_CHECKER;
             kind = light ? (checker ? MK_LIGHT_CHECKER : MK_LIGHT_SOLID) : (checker ? MK_LAMBERT_CHECKER : MK_LAMBERT_SOLID);
-            if (t) {
+            if (t && t->type == RT_TEX_IMAGE) {
+                kind = light ? MK_LIGHT_IMAGE : MK_LAMBERT_IMAGE;
+                const size_t im = (size_t)t->c0[0];
+                q[4] = bits(image_word[im]), q[5] = bits(s.images[im].rows), q[6] = bits(s.images[im].cols);
+            } else if (t) {
                 q[4] = t->c0[0], q[5] = t->c0[1], q[6] = t->c0[2];
                 q[8] = t->c1[0], q[9] = t->c1[1], q[10] = t->c1[2];
             }
@@ -582,6 +631,13 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         set_error("unknown kernel variant %u", variant);
         return RT_ERR_ARG;
     }
+    // triangles and image textures live in separate builds of the kernels (template argument EXT)
+    bool ext = !s.images.empty();
+    for (const rt_prim &p : s.prims) ext = ext || p.type == RT_PRIM_TRIANGLE;
+    if (ext && count) {
+        set_error("the counting kernel has no build with triangles / image textures");
+        return RT_ERR_LIMIT;
+    }
     int device = o ? o->device : 0;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -676,6 +732,10 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     if (variant == 0 && hot_bytes > global_threshold) variant = 40;
     if (variant == 64 && hot_bytes > global_threshold) variant = 104;
     hot_bytes = hot_bytes_of(variant);
+    if (ext && !variant_has_ext(variant)) {
+        set_error("kernel variant %u has no build with triangles / image textures (variants 0, 16 and 40 have)", variant);
+        return RT_ERR_LIMIT;
+    }
     const size_t lds_bytes = ((variant & 8u) ? 0 : hot_bytes) + acc_lds;
     if (lds_bytes > 160 * 1024) {
         set_error("kernel variant %u keeps the scene tables in LDS and this scene needs %zu bytes per workgroup "
@@ -705,7 +765,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ent->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const unsigned long long resident = (unsigned long long)ent->num_cus * blocks_per_cu(variant, count, lds_bytes, P.cluster);
+    const unsigned long long resident = (unsigned long long)ent->num_cus * blocks_per_cu(variant, count, lds_bytes, P.cluster, ext);
     const unsigned long long need_blocks = (items64 + 3) / 4;
     const unsigned long long grid64 = need_blocks < resident ? (need_blocks ? need_blocks : 1) : resident;
 
@@ -757,9 +817,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         // nothing worth culling (no sphere clusters, a handful of cylinders): the plain scan is the
         // same result without the per-query box set-up
         unsigned launch_variant = variant;
-        if (!count && (variant & 16u) == 0 && P.ncl == 0 && P.nc < 4 && variant_exists(variant | 16u)) launch_variant = variant | 16u;
+        if (!count && (variant & 16u) == 0 && P.ncl == 0 && P.nc < 4 && P.nt < 4 && variant_exists(variant | 16u) &&
+            (!ext || variant_has_ext(variant | 16u)))
+            launch_variant = variant | 16u;
         if (s.max_depth > 0) {
-            launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, launch_variant);
+            launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, launch_variant, ext);
             ++launches;
         }
         if (d_out) {

@@ -44,6 +44,7 @@
 
 #include "device_scene.h"
 #include "philox.h"
+#include "rt_trig.h"
 #include "../../include/rtmi.h"
 
 // minimum resident waves per SIMD the register allocator must leave room for (8 <=> 64 VGPRs)
@@ -114,11 +115,29 @@ __device__ __forceinline__ bool checker_odd(float px, float py, float pz) {
     return !zero && (((kx + ky + kz) & 1) != 0);
 }
 
+// a x b, one fused multiply-add per component (the checker uses the same form)
+__device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, float by, float bz, float &cx, float &cy, float &cz) {
+    cx = fmaf(ay, bz, -(az * by));
+    cy = fmaf(az, bx, -(ax * bz));
+    cz = fmaf(ax, by, -(ay * bx));
+}
+
+// image texture, taichi-version/material.py:137-144: texel[int(frac(u) * rows)][int(frac(v) * cols)] / 255
+__device__ __forceinline__ void image_texel(const float4 *__restrict__ image, const float4 q1, float u, float v, float &r, float &g,
+                                            float &b) {
+    const int rows = __float_as_int(q1.y), cols = __float_as_int(q1.z);
+    const int x = min((int)((u - floorf(u)) * (float)rows), rows - 1);
+    const int y = min((int)((v - floorf(v)) * (float)cols), cols - 1);
+    const uint32_t w = reinterpret_cast<const uint32_t *>(image)[__float_as_int(q1.x) + x * cols + y];
+    r = (float)(w & 255u) / 255.0f, g = (float)((w >> 8) & 255u) / 255.0f, b = (float)((w >> 16) & 255u) / 255.0f;
+}
+
 // original list index of a grouped primitive id (cold tables), for the tie rule
 __device__ __forceinline__ int list_index_of(const RenderParams &P, const float4 *__restrict__ image, int id) {
     if (id < P.ns) return __float_as_int(image[P.off_sph_cold + id].z);
     if (id < P.ns + P.nr) return __float_as_int(image[P.off_rect_cold + (id - P.ns)].y);
-    return __float_as_int(image[P.off_cyl_cold + 4 * (id - P.ns - P.nr) + 3].y);
+    if (id < P.ns + P.nr + P.nc) return __float_as_int(image[P.off_cyl_cold + 4 * (id - P.ns - P.nr) + 3].y);
+    return __float_as_int(image[P.off_tri_cold + 2 * (id - P.ns - P.nr - P.nc)].y);
 }
 
 // radiance sample -> 64-bit fixed point with RT_FIX_BITS (24) fractional bits, round to nearest even;
@@ -161,7 +180,10 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 // CSIZE:    spheres per cluster (8 or 16: the packer picks per scene, RenderParams::cluster); a cluster occupies
 //           CSIZE + 1 slots (the last one never hit), which keeps the per-lane reads of different clusters on
 //           different LDS banks
-template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL, int CSIZE>
+// EXT:      the Taichi renderer's extras -- triangles (taichi-version/hittable.py:38-71) and image textures read at the
+//           hit record's (u, v) (material.py:137-144).  Only the builds for scenes that use them carry the code: it
+//           costs the kernel its register budget (86 spilled VGPRs instead of 23) whether a scene uses it or not.
+template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL, int CSIZE, bool EXT = false>
 __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SIMD)) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
                                                      unsigned int *__restrict__ queue,
@@ -182,7 +204,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     const float4 *sph = hot;
     const float4 *rect = hot + P.off_rect_hot;
     const float4 *cyl = hot + P.off_cyl_hot;
-    const int ns = P.ns, nr = P.nr, nc = P.nc;
+    const int ns = P.ns, nr = P.nr, nc = P.nc, nt = P.nt;
+    const float4 *tri = hot + P.off_tri_hot;
     const float wm1 = (float)(P.width - 1), hm1 = (float)(P.height - 1);
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
@@ -290,6 +313,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, inv_len = 0;
         int mat = 0, kind = -1;  // kind >= 0: a scatter step is due in (6)
         bool front = false;
+        float tex_r = 0, tex_g = 0, tex_b = 0;  // the texel of an image texture at the hit's (u, v)
         if (__any(active)) {
         if (active) {
             // ---- closest-hit query over the LDS-resident list (hittable_list::hit,
@@ -322,6 +346,22 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         best_id = idx;
                     }
                 }
+            };
+            // the point where the ray meets a triangle's plane and its ray parameter (hittable.py:44-52, 61):
+            // n = the unit normal turned towards the origin, theta = d.n / |d| < 0, r = o - d/|d| (oc.n) / theta
+            auto tri_plane = [&](const float4 r0, const float4 r1, const float4 r2, float &rix, float &riy, float &riz,
+                                 float &root) -> bool {
+                float tnx = r0.w, tny = r1.w, tnz = r2.w;
+                float ocn = dot3(ox - r0.x, oy - r0.y, oz - r0.z, tnx, tny, tnz);
+                if (ocn < 0.0f) tnx = -tnx, tny = -tny, tnz = -tnz, ocn = -ocn;
+                const float a = sqrtf(ra);
+                const float theta = dot3(dx, dy, dz, tnx, tny, tnz) / a;
+                if (!(theta < 0.0f)) return false;
+                rix = ox - ((dx / a) * ocn) / theta;
+                riy = oy - ((dy / a) * ocn) / theta;
+                riz = oz - ((dz / a) * ocn) / theta;
+                root = ((-ocn) / theta) / a;
+                return true;
             };
 #define RT_SPHERE_TEST(S, IDX)                                                                 \
     {                                                                                          \
@@ -669,6 +709,46 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     }
                 }
             }
+            // triangles: hit_triangle, taichi-version/hittable.py:38-71 -- the plane of the triangle (its unit normal
+            // turned towards the ray origin), then four same-side tests of the plane point
+            for (int k = 0; EXT && k < nt; ++k) {
+                if (CULL) {
+                    blim = best_t * 1.0001f;
+                    const float4 *tb = hot + P.off_tbox + 2 * k;
+                    if (__builtin_amdgcn_ballot_w64(slab_live(tb[0], tb[1])) == 0ull) continue;
+                }
+                const float4 r0 = tri[3 * k], r1 = tri[3 * k + 1], r2 = tri[3 * k + 2];
+                float rix, riy, riz, root;
+                if (tri_plane(r0, r1, r2, rix, riy, riz, root) && !(root < kTMin || root > best_t)) {
+                    const float e21x = r1.x - r0.x, e21y = r1.y - r0.y, e21z = r1.z - r0.z;
+                    const float e31x = r2.x - r0.x, e31y = r2.y - r0.y, e31z = r2.z - r0.z;
+                    const float e32x = r2.x - r1.x, e32y = r2.y - r1.y, e32z = r2.z - r1.z;
+                    const float a1x = rix - r0.x, a1y = riy - r0.y, a1z = riz - r0.z;
+                    const float a2x = rix - r1.x, a2y = riy - r1.y, a2z = riz - r1.z;
+                    float px_, py_, pz_, qx_, qy_, qz_;
+                    cross3(a1x, a1y, a1z, e21x, e21y, e21z, px_, py_, pz_);
+                    cross3(e31x, e31y, e31z, e21x, e21y, e21z, qx_, qy_, qz_);
+                    const float n1 = dot3(px_, py_, pz_, qx_, qy_, qz_);
+                    cross3(a2x, a2y, a2z, -e21x, -e21y, -e21z, px_, py_, pz_);
+                    cross3(e32x, e32y, e32z, -e21x, -e21y, -e21z, qx_, qy_, qz_);
+                    const float n2 = dot3(px_, py_, pz_, qx_, qy_, qz_);
+                    cross3(a1x, a1y, a1z, e31x, e31y, e31z, px_, py_, pz_);
+                    cross3(e21x, e21y, e21z, e31x, e31y, e31z, qx_, qy_, qz_);
+                    const float n3 = dot3(px_, py_, pz_, qx_, qy_, qz_);
+                    cross3(a2x, a2y, a2z, e32x, e32y, e32z, px_, py_, pz_);
+                    cross3(-e21x, -e21y, -e21z, e32x, e32y, e32z, qx_, qy_, qz_);
+                    const float n4 = dot3(px_, py_, pz_, qx_, qy_, qz_);
+                    if (n1 > 0.0f && n2 > 0.0f && n3 > 0.0f && n4 > 0.0f) {
+                        bool take = true;
+                        if (root == best_t && best_id >= 0)
+                            take = list_index_of(P, image, ns + nr + nc + k) > list_index_of(P, image, best_id);
+                        if (take) {
+                            best_t = root;
+                            best_id = ns + nr + nc + k;
+                        }
+                    }
+                }
+            }
             if (COUNT) {
                 c_queries++;
                 if ((int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) == lane) c_wave_queries++;
@@ -698,7 +778,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const float sgn = front ? 1.0f : -1.0f, zer = front ? 0.0f : -0.0f;
                     nx = axis == 2 ? sgn : zer, ny = axis == 1 ? sgn : zer, nz = axis == 0 ? sgn : zer;
                     mat = __float_as_int(image[P.off_rect_cold + j].x);
-                } else {
+                } else if (best_id < ns + nr + nc) {
                     const int k = best_id - ns - nr;
                     const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2];
                     const float4 *cc4 = image + P.off_cyl_cold + 4 * k;
@@ -721,13 +801,74 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     front = dot3(dx, dy, dz, wnx, wny, wnz) < 0.0f;
                     nx = front ? wnx : -wnx, ny = front ? wny : -wny, nz = front ? wnz : -wnz;
                     mat = __float_as_int(cc4[3].x);
+                } else if (EXT) {  // triangle, taichi-version/hittable.py:254-259: the stored unit normal, turned against the ray
+                    const int k = best_id - ns - nr - nc;
+                    const float tnx = tri[3 * k].w, tny = tri[3 * k + 1].w, tnz = tri[3 * k + 2].w;
+                    px = fmaf(best_t, dx, ox), py = fmaf(best_t, dy, oy), pz = fmaf(best_t, dz, oz);
+                    front = dot3(dx, dy, dz, tnx, tny, tnz) < 0.0f;
+                    nx = front ? tnx : -tnx, ny = front ? tny : -tny, nz = front ? tnz : -tnz;
+                    mat = __float_as_int(image[P.off_tri_cold + 2 * k].x);
                 }
-
                 const float4 *M = image + P.off_mat + 3 * mat;
                 kind = __float_as_int(M[0].x);
+                // the hit record's (u, v) -- only where the material's texture reads them (an image texture); every
+                // other texture of the reference ignores them, and acos / atan2 per candidate hit (object.cuh:87-93)
+                // would be the most expensive part of sphere::hit
+                if (EXT && (kind == MK_LAMBERT_IMAGE || kind == MK_LIGHT_IMAGE)) {
+                    float tu, tv;
+                    if (best_id < ns) {  // get_sphere_uv(outward_normal), object.cuh:87-93
+                        const float onx = front ? nx : -nx, ony = front ? ny : -ny, onz = front ? nz : -nz;
+                        const float theta = rt_acosf(-ony);
+                        const float phi = rt_atan2f(-onz, onx) + 3.1415927410125732421875f;
+                        tu = phi / 6.283185482025146484375f;
+                        tv = theta / 3.1415927410125732421875f;
+                    } else if (best_id < ns + nr) {  // object.cuh:113-114, 150-151, 183-184
+                        const int j = best_id - ns;
+                        const float4 q0r = rect[2 * j];
+                        const int axis = __float_as_int(rect[2 * j + 1].y);
+                        const float pa = axis == 2 ? py : px, pb = axis == 0 ? py : pz;
+                        tu = (pa - q0r.x) / (q0r.y - q0r.x);
+                        tv = (pb - q0r.z) / (q0r.w - q0r.z);
+                    } else if (best_id < ns + nr + nc) {  // object.cuh:283-288, in the cylinder's object space
+                        const int k = best_id - ns - nr;
+                        const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2], pr = cyl[4 * k + 3];
+                        const float oox = fmaf(r0.x, ox, fmaf(r0.y, oy, fmaf(r0.z, oz, r0.w)));
+                        const float ooy = fmaf(r1.x, ox, fmaf(r1.y, oy, fmaf(r1.z, oz, r1.w)));
+                        const float ooz = fmaf(r2.x, ox, fmaf(r2.y, oy, fmaf(r2.z, oz, r2.w)));
+                        const float odx = fmaf(r0.x, dx, fmaf(r0.y, dy, r0.z * dz));
+                        const float ody = fmaf(r1.x, dx, fmaf(r1.y, dy, r1.z * dz));
+                        const float odz = fmaf(r2.x, dx, fmaf(r2.y, dy, r2.z * dz));
+                        const float opx = fmaf(best_t, odx, oox), opy = fmaf(best_t, ody, ooy), opz = fmaf(best_t, odz, ooz);
+                        const float phi = rt_atan2f(opy, opx) + 6.283185482025146484375f;
+                        tu = phi / 12.56637096405029296875f;
+                        tv = (opz - pr.y) / (pr.z - pr.y);
+                    } else {  // hittable.py:54-58, 233: area weights of the plane point, uv = u1 w1 + u2 w2 + u3 w3
+                        const int k = best_id - ns - nr - nc;
+                        const float4 r0 = tri[3 * k], r1 = tri[3 * k + 1], r2 = tri[3 * k + 2];
+                        float rix, riy, riz, root;
+                        tri_plane(r0, r1, r2, rix, riy, riz, root);
+                        const float a1x = rix - r0.x, a1y = riy - r0.y, a1z = riz - r0.z;
+                        const float a2x = rix - r1.x, a2y = riy - r1.y, a2z = riz - r1.z;
+                        const float a3x = rix - r2.x, a3y = riy - r2.y, a3z = riz - r2.z;
+                        float cx, cy, cz, ex, ey, ez;
+                        cross3(a1x, a1y, a1z, a2x, a2y, a2z, cx, cy, cz);
+                        cross3(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z, r2.x - r1.x, r2.y - r1.y, r2.z - r1.z, ex, ey, ez);
+                        const float w1 = sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+                        cross3(a1x, a1y, a1z, a3x, a3y, a3z, cx, cy, cz);
+                        cross3(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z, r1.x - r2.x, r1.y - r2.y, r1.z - r2.z, ex, ey, ez);
+                        const float w2 = sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+                        cross3(a3x, a3y, a3z, a2x, a2y, a2z, cx, cy, cz);
+                        cross3(r0.x - r2.x, r0.y - r2.y, r0.z - r2.z, r0.x - r1.x, r0.y - r1.y, r0.z - r1.z, ex, ey, ez);
+                        const float w3 = sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+                        const float4 c0 = image[P.off_tri_cold + 2 * k], c1 = image[P.off_tri_cold + 2 * k + 1];
+                        tu = fmaf(c1.z, w3, fmaf(c1.x, w2, c0.z * w1));
+                        tv = fmaf(c1.w, w3, fmaf(c1.y, w2, c0.w * w1));
+                    }
+                    image_texel(image, M[1], tu, tv, tex_r, tex_g, tex_b);
+                }
                 if (COUNT) {
                     c_hits++;
-                    if (kind <= MK_LAMBERT_CHECKER) c_scatter0++;
+                    if (kind <= MK_LAMBERT_IMAGE) c_scatter0++;
                     else if (kind == MK_METAL) c_scatter1++;
                     else if (kind == MK_DIELECTRIC) c_scatter2++;
                     else c_scatter3++;
@@ -735,7 +876,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 if (kind >= MK_LIGHT_SOLID) {  // diffuse_light: emitted, never scatters (material.cuh:161-182, main.cu:48-58)
                     const float4 q1 = M[1], q2 = M[2];
                     const bool odd = kind == MK_LIGHT_CHECKER && checker_odd(px, py, pz);
-                    const float er = odd ? q2.x : q1.x, eg = odd ? q2.y : q1.y, eb = odd ? q2.z : q1.z;
+                    float er = odd ? q2.x : q1.x, eg = odd ? q2.y : q1.y, eb = odd ? q2.z : q1.z;
+                    if (EXT && kind == MK_LIGHT_IMAGE) er = tex_r, eg = tex_g, eb = tex_b;
                     L_r = fmaf(er, beta_r, L_r), L_g = fmaf(eg, beta_g, L_g), L_b = fmaf(eb, beta_b, L_b);
                     path_done = true;  // absorbed: main.cu:55-58
                     kind = -1;
@@ -910,13 +1052,14 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 float ndx, ndy, ndz;           // scattered direction
                 float at_r, at_g, at_b;        // attenuation
                 bool scattered = true;
-                if (kind <= MK_LAMBERT_CHECKER) {  // lambertian::scatter, material.h:25-35
+                if (kind <= MK_LAMBERT_IMAGE) {  // lambertian::scatter, material.h:25-35
                     const float inv = 1.0f / sqrtf(sl2);
                     ndx = nx + inv * sx, ndy = ny + inv * sy, ndz = nz + inv * sz;
                     const float eps = 1e-8f;
                     if (fabsf(ndx) < eps && fabsf(ndy) < eps && fabsf(ndz) < eps) ndx = nx, ndy = ny, ndz = nz;
                     const bool odd = kind == MK_LAMBERT_CHECKER && checker_odd(px, py, pz);
                     at_r = odd ? q2.x : q1.x, at_g = odd ? q2.y : q1.y, at_b = odd ? q2.z : q1.z;
+                    if (EXT && kind == MK_LAMBERT_IMAGE) at_r = tex_r, at_g = tex_g, at_b = tex_b;
                 } else if (kind == MK_METAL) {  // metal::scatter, material.h:47-53
                     const float ux = inv_len * dx, uy = inv_len * dy, uz = inv_len * dz;
                     const float k2 = 2.0f * dot3(ux, uy, uz, nx, ny, nz);
@@ -1084,12 +1227,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
     X(40, true, true, true, 3)     \
     X(64, true, true, false, 2)    \
     X(104, true, true, true, 2)
+// variants that also exist with EXT (triangles, image textures): the default, its global-table form, the flat scan
+#define RT_EXT_TABLE(X)            \
+    X(0, true, true, false, 3)     \
+    X(16, true, true, false, 0)    \
+    X(40, true, true, true, 3)
 // every variant exists for both cluster sizes (the linear scans ignore it)
 #define RT_WITH_CSIZE(CALL8, CALL16) \
     if (cluster == 16) { CALL16; } else { CALL8; }
 
 void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
-                   DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant) {
+                   DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant, bool ext) {
     const float4 *img = (const float4 *)image;
     const dim3 g(grid), t(256);
     const int cluster = P.cluster;
@@ -1104,6 +1252,19 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
         return;
     }
     DevCounters *none = nullptr;
+    if (ext) {
+#define RT_LAUNCH_EXT(V, POOL, PRE, SCALAR, CULL)                                                                                          \
+    case V:                                                                                                                                 \
+        RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 8, true>), g, t, lds_bytes, stream, P, img, acc, queue, none),  \
+                      hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 16, true>), g, t, lds_bytes, stream, P, img, acc, queue, none)) \
+        break;
+        switch (variant) {
+            RT_EXT_TABLE(RT_LAUNCH_EXT)
+        default: break;
+        }
+#undef RT_LAUNCH_EXT
+        return;
+    }
 #define RT_LAUNCH(V, POOL, PRE, SCALAR, CULL)                                                                                              \
     case V:                                                                                                                                 \
         RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 8>), g, t, lds_bytes, stream, P, img, acc, queue, none),  \
@@ -1118,10 +1279,18 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
 
 // resident workgroups per CU of a variant at this dynamic-LDS size (advisory; an over-estimate only
 // leaves late workgroups that find the queue empty)
-int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster) {
+int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster, bool ext) {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
-    if (count) {
+    if (ext) {
+#define RT_OCC_EXT(V, POOL, PRE, SCALAR, CULL)                                                                                              \
+    if (variant == V) {                                                                                                                      \
+        RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL, 8, true>, 256, lds_bytes), \
+                      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL, 16, true>, 256, lds_bytes)) \
+    }
+        RT_EXT_TABLE(RT_OCC_EXT)
+#undef RT_OCC_EXT
+    } else if (count) {
 #define RT_COUNT_OCC(SCALAR, CULL)                                                                                                          \
     RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 8>, 256, lds_bytes),   \
                   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 16>, 256, lds_bytes))
@@ -1148,6 +1317,15 @@ int variant_cull_mode(unsigned variant) {
     RT_VARIANT_TABLE(RT_MODE)
 #undef RT_MODE
     return -1;
+}
+
+// does the variant have a build with triangles and image textures?
+bool variant_has_ext(unsigned variant) {
+#define RT_HAS_EXT(V, POOL, PRE, SCALAR, CULL) \
+    if (variant == V) return true;
+    RT_EXT_TABLE(RT_HAS_EXT)
+#undef RT_HAS_EXT
+    return false;
 }
 
 bool variant_exists(unsigned variant) {
@@ -1183,6 +1361,11 @@ int set_max_dynamic_lds(size_t bytes) {
     RT_ATTR1((render_kernel<true, true, true, false, 3, 16>))
     RT_ATTR1((render_kernel<true, true, true, false, 2, 8>))
     RT_ATTR1((render_kernel<true, true, true, false, 2, 16>))
+#define RT_ATTR_EXT(V, POOL, PRE, SCALAR, CULL)                        \
+    RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 8, true>)) \
+    RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 16, true>))
+    RT_EXT_TABLE(RT_ATTR_EXT)
+#undef RT_ATTR_EXT
 #define RT_ATTR(V, POOL, PRE, SCALAR, CULL)                      \
     RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 8>)) \
     RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 16>))

@@ -1,6 +1,8 @@
 // Scene construction: JSON -> tables, RTIOW generator, camera derivation, JSON out.
 #include "scene.hpp"
 
+#include <array>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -161,8 +163,26 @@ int scene_validate(const Scene &s) {
             }
         }
     }
+    for (size_t i = 0; i < s.texs.size(); ++i) {
+        const rt_texture &t = s.texs[i];
+        if (t.type == RT_TEX_IMAGE) {
+            const int im = (int)t.c0[0];
+            if (im < 0 || im >= (int)s.images.size() || s.images[im].rows != (int)t.c0[1] || s.images[im].cols != (int)t.c0[2] ||
+                s.images[im].rgb.size() != (size_t)s.images[im].rows * s.images[im].cols * 3) {
+                set_error("texture %zu references image %d, which is missing or has another size", i, im);
+                return RT_ERR_SCENE;
+            }
+        } else if (t.type != RT_TEX_SOLID && t.type != RT_TEX_CHECKER) {
+            set_error("texture %zu has unknown type %d", i, t.type);
+            return RT_ERR_SCENE;
+        }
+    }
     for (size_t i = 0; i < s.prims.size(); ++i) {
         const rt_prim &p = s.prims[i];
+        if (p.type < RT_PRIM_SPHERE || p.type > RT_PRIM_TRIANGLE) {
+            set_error("object %zu has unknown type %d", i, p.type);
+            return RT_ERR_SCENE;
+        }
         if (p.material < 0 || p.material >= (int)s.mats.size()) {
             set_error("object %zu references material %d (have %zu)", i, p.material, s.mats.size());
             return RT_ERR_SCENE;
@@ -179,6 +199,212 @@ int scene_validate(const Scene &s) {
         return RT_ERR_SCENE;
     }
     return RT_OK;
+}
+
+// ---------------------------------------------------------------- image textures, triangles, meshes
+int add_image_texture(Scene &s, int rows, int cols, const uint8_t *rgb, const std::string &file) {
+    if (rows < 1 || cols < 1 || rows > 16384 || cols > 16384 || !rgb) {
+        set_error("image texture: rows and cols must be in 1..16384 and the pixels not null (got %d x %d)", rows, cols);
+        return -RT_ERR_ARG;
+    }
+    SceneImage im;
+    im.rows = rows, im.cols = cols, im.file = file;
+    im.rgb.assign(rgb, rgb + (size_t)rows * cols * 3);
+    s.images.push_back(std::move(im));
+    rt_texture t;
+    memset(&t, 0, sizeof t);
+    t.type = RT_TEX_IMAGE;
+    t.c0[0] = (float)(s.images.size() - 1), t.c0[1] = (float)rows, t.c0[2] = (float)cols;
+    s.texs.push_back(t);
+    s.touch();
+    return (int)s.texs.size() - 1;
+}
+
+// P6 (binary) or P3 (text) PPM with maxval 255; '#' comments allowed in the header
+static int read_ppm(const char *path, int &rows, int &cols, std::vector<uint8_t> &rgb) {
+    FILE *fp = fopen(path, "rb");
+    if (!fp) {
+        set_error("cannot open %s", path);
+        return RT_ERR_IO;
+    }
+    std::vector<unsigned char> buf;
+    unsigned char chunk[65536];
+    size_t n;
+    while ((n = fread(chunk, 1, sizeof chunk, fp)) > 0) buf.insert(buf.end(), chunk, chunk + n);
+    fclose(fp);
+    size_t pos = 0;
+    auto token = [&](long &out) -> bool {  // next unsigned integer of the header / a P3 body
+        for (;;) {
+            while (pos < buf.size() && isspace(buf[pos])) ++pos;
+            if (pos < buf.size() && buf[pos] == '#') {
+                while (pos < buf.size() && buf[pos] != '\n') ++pos;
+                continue;
+            }
+            break;
+        }
+        if (pos >= buf.size() || !isdigit(buf[pos])) return false;
+        long v = 0;
+        while (pos < buf.size() && isdigit(buf[pos])) {
+            v = v * 10 + (buf[pos++] - '0');
+            if (v > 100000000) return false;
+        }
+        out = v;
+        return true;
+    };
+    if (buf.size() < 2 || buf[0] != 'P' || (buf[1] != '6' && buf[1] != '3')) {
+        set_error("%s is not a PPM file (P6 or P3)", path);
+        return RT_ERR_IO;
+    }
+    const bool binary = buf[1] == '6';
+    pos = 2;
+    long w = 0, h = 0, mx = 0;
+    if (!token(w) || !token(h) || !token(mx) || w < 1 || h < 1 || w > 16384 || h > 16384 || mx != 255) {
+        set_error("%s: unsupported PPM header (need width, height <= 16384 and maxval 255)", path);
+        return RT_ERR_IO;
+    }
+    rows = (int)h, cols = (int)w;
+    const size_t need = (size_t)w * h * 3;
+    rgb.resize(need);
+    if (binary) {
+        ++pos;  // the single whitespace byte after maxval
+        if (buf.size() - pos < need) {
+            set_error("%s is truncated", path);
+            return RT_ERR_IO;
+        }
+        memcpy(rgb.data(), buf.data() + pos, need);
+    } else {
+        for (size_t i = 0; i < need; ++i) {
+            long v = 0;
+            if (!token(v) || v > 255) {
+                set_error("%s: bad or missing sample %zu", path, i);
+                return RT_ERR_IO;
+            }
+            rgb[i] = (uint8_t)v;
+        }
+    }
+    return RT_OK;
+}
+
+int add_image_texture_file(Scene &s, const char *path) {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> rgb;
+    int rc = read_ppm(path, rows, cols, rgb);
+    if (rc) return -rc;
+    return add_image_texture(s, rows, cols, rgb.data(), path);
+}
+
+// Triangle.__init__, taichi-version/hittable.py:95-110: the unit normal (v2 - v1) x (v3 - v1) / |..| is a
+// constructor value there too; derived in fp64 from the fp32 vertices and rounded once
+int add_triangle(Scene &s, const float v1[3], const float v2[3], const float v3[3], const float uv1[2], const float uv2[2],
+                 const float uv3[2], int material) {
+    double a[3], b[3], n[3];
+    for (int k = 0; k < 3; ++k) a[k] = (double)v2[k] - (double)v1[k], b[k] = (double)v3[k] - (double)v1[k];
+    v3cross(a, b, n);
+    const double len = v3len(n);
+    if (!(len > 0) || !std::isfinite(len)) {
+        set_error("triangle with zero area (or non-finite vertices)");
+        return -RT_ERR_SCENE;
+    }
+    rt_prim p;
+    memset(&p, 0, sizeof p);
+    p.type = RT_PRIM_TRIANGLE;
+    p.material = material;
+    for (int k = 0; k < 3; ++k) {
+        p.m[k] = v1[k], p.m[3 + k] = v2[k], p.m[6 + k] = v3[k];
+        p.m[9 + k] = (float)(n[k] / len);
+    }
+    const float *uv[3] = {uv1, uv2, uv3};
+    for (int c = 0; c < 3; ++c)
+        if (uv[c]) p.m_inv[2 * c] = uv[c][0], p.m_inv[2 * c + 1] = uv[c][1];
+    s.prims.push_back(p);
+    s.xforms.emplace_back();
+    s.touch();
+    return (int)s.prims.size() - 1;
+}
+
+// readobj(), taichi-version/main.py:23-41, and the placement of main.py:110-118 (scale * Rot @ x + dis)
+int add_obj(Scene &s, const char *path, int material, float scale, const float matrix[9], const float translate[3]) {
+    FILE *fp = fopen(path, "r");
+    if (!fp) {
+        set_error("cannot open %s", path);
+        return -RT_ERR_IO;
+    }
+    std::vector<std::array<float, 3>> pts;
+    std::vector<std::array<float, 2>> vts;
+    struct Corner {
+        long v, t;
+    };
+    std::vector<std::array<Corner, 3>> faces;
+    char line[1024];
+    int lineno = 0;
+    bool bad = false;
+    while (fgets(line, sizeof line, fp)) {
+        ++lineno;
+        char *p = line;
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            double x, y, z;
+            if (sscanf(p + 1, "%lf %lf %lf", &x, &y, &z) != 3) bad = true;
+            else pts.push_back({(float)x, (float)y, (float)z});
+        } else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) {
+            double u, v;
+            if (sscanf(p + 2, "%lf %lf", &u, &v) != 2) bad = true;
+            else vts.push_back({(float)u, (float)v});
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            std::array<Corner, 3> f;
+            char *q = p + 1;
+            int got = 0;
+            for (; got < 3; ++got) {
+                while (*q == ' ' || *q == '\t') ++q;
+                char *e;
+                long vi = strtol(q, &e, 10), ti = 0;
+                if (e == q) break;
+                q = e;
+                if (*q == '/') {  // a/t or a/t/n or a//n
+                    ++q;
+                    ti = strtol(q, &e, 10);
+                    q = e;
+                    if (*q == '/') {
+                        ++q;
+                        (void)strtol(q, &e, 10);
+                        q = e;
+                    }
+                }
+                f[got] = {vi, ti ? ti : vi};  // without vt indices the reference takes texids[face corner]
+            }
+            if (got != 3) bad = true;
+            else faces.push_back(f);
+        }
+        if (bad) break;
+    }
+    fclose(fp);
+    if (bad) {
+        set_error("%s:%d: cannot parse this line", path, lineno);
+        return -RT_ERR_IO;
+    }
+    int added = 0;
+    for (const auto &f : faces) {
+        float v[3][3], uv[3][2];
+        for (int c = 0; c < 3; ++c) {
+            const long vi = f[c].v, ti = f[c].t;
+            if (vi < 1 || vi > (long)pts.size()) {
+                set_error("%s: face refers to vertex %ld (have %zu)", path, vi, pts.size());
+                return -RT_ERR_SCENE;
+            }
+            const auto &x = pts[vi - 1];
+            for (int r = 0; r < 3; ++r) {
+                double m = matrix ? (double)matrix[3 * r] * x[0] + (double)matrix[3 * r + 1] * x[1] + (double)matrix[3 * r + 2] * x[2]
+                                  : (double)x[r];
+                v[c][r] = (float)((double)scale * m + (translate ? (double)translate[r] : 0.0));
+            }
+            uv[c][0] = uv[c][1] = 0.0f;
+            if (ti >= 1 && ti <= (long)vts.size()) uv[c][0] = vts[ti - 1][0], uv[c][1] = vts[ti - 1][1];
+        }
+        int rc = add_triangle(s, v[0], v[1], v[2], uv[0], uv[1], uv[2], material);
+        if (rc < 0) return rc;
+        ++added;
+    }
+    return added;
 }
 
 // ---------------------------------------------------------------- JSON in
@@ -237,7 +463,11 @@ struct Reader {
 
 }  // namespace
 
-int scene_from_json(const char *text, size_t len, Scene &s) {
+int scene_from_json(const char *text, size_t len, Scene &s, const char *base_dir) {
+    auto resolve = [&](const std::string &file) {  // relative "file" entries: next to the scene file
+        if (file.empty() || file[0] == '/' || !base_dir || !*base_dir) return file;
+        return std::string(base_dir) + "/" + file;
+    };
     JsonValue root;
     std::string perr;
     JsonParser parser(text, len);
@@ -323,6 +553,33 @@ int scene_from_json(const char *text, size_t len, Scene &s) {
                 for (int k = 0; k < 3; ++k) rec.c0[k] = (float)c[k];
                 r.vec3(t, "odd", where, c);
                 for (int k = 0; k < 3; ++k) rec.c1[k] = (float)c[k];
+            } else if (ty->str == "image") {
+                // taichi-version/material.py:137-144 (one 100 x 100 image there, read with cv2 at hittable.py:165-172)
+                int id = -1;
+                if (const JsonValue *f = t.find("file")) {
+                    if (!f->is_string()) r.fail("%s: \"file\" must be a string", where);
+                    else {
+                        id = add_image_texture_file(s, resolve(f->str).c_str());
+                        if (id >= 0) s.images.back().file = f->str;  // serialised as given
+                    }
+                } else {
+                    const int rows = r.integer(t, "rows", where), cols = r.integer(t, "cols", where);
+                    const JsonValue *d = t.find("data");
+                    if (r.ok && (!d || !d->is_array() || rows < 1 || cols < 1 || d->arr.size() != (size_t)rows * cols * 3))
+                        r.fail("%s: \"data\" must be an array of rows * cols * 3 bytes", where);
+                    if (r.ok) {
+                        std::vector<uint8_t> px(d->arr.size());
+                        for (size_t k = 0; k < px.size() && r.ok; ++k) {
+                            const JsonValue &v = d->arr[k];
+                            if (!v.is_number() || v.num < 0 || v.num > 255 || v.num != std::floor(v.num))
+                                r.fail("%s: \"data\"[%zu] is not a byte", where, k);
+                            else px[k] = (uint8_t)v.num;
+                        }
+                        if (r.ok) id = add_image_texture(s, rows, cols, px.data(), "");
+                    }
+                }
+                if (r.ok && id < 0) return -id;
+                continue;  // add_image_texture appended the texture record
             } else {
                 r.fail("%s: unknown type \"%s\"", where, ty->str.c_str());
             }
@@ -426,6 +683,52 @@ int scene_from_json(const char *text, size_t len, Scene &s) {
                     int rc = add_cylinder(s, radius, zmin, zmax, mat, pa, deg, po);
                     if (rc < 0) return RT_ERR_SCENE;
                 }
+            } else if (t == "triangle") {  // taichi-version/hittable.py:95-110
+                double v[3][3], u[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                r.vec3(o, "v1", where, v[0]), r.vec3(o, "v2", where, v[1]), r.vec3(o, "v3", where, v[2]);
+                const char *uk[3] = {"u1", "u2", "u3"};
+                for (int c = 0; c < 3; ++c)
+                    if (const JsonValue *uv = o.find(uk[c])) {
+                        if (!uv->is_array() || uv->arr.size() < 2 || !uv->arr[0].is_number() || !uv->arr[1].is_number())
+                            r.fail("%s: \"%s\" must be an array of 2 numbers", where, uk[c]);
+                        else u[c][0] = uv->arr[0].num, u[c][1] = uv->arr[1].num;
+                    }
+                const int mat = r.integer(o, "material", where);
+                if (r.ok) {
+                    float vf[3][3], uf[3][2];
+                    for (int c = 0; c < 3; ++c) {
+                        for (int k = 0; k < 3; ++k) vf[c][k] = (float)v[c][k];
+                        uf[c][0] = (float)u[c][0], uf[c][1] = (float)u[c][1];
+                    }
+                    if (add_triangle(s, vf[0], vf[1], vf[2], uf[0], uf[1], uf[2], mat) < 0) return RT_ERR_SCENE;
+                }
+            } else if (t == "mesh") {  // readobj + placement, taichi-version/main.py:23-41, 110-118
+                const JsonValue *f = o.find("file");
+                if (!f || !f->is_string()) r.fail("%s: missing string \"file\"", where);
+                const int mat = r.integer(o, "material", where);
+                float scale = 1.0f, M[9], T[3];
+                const float *pm = nullptr, *pt = nullptr;
+                if (o.find("scale")) scale = (float)r.num(o, "scale", where);
+                if (const JsonValue *m = o.find("matrix")) {
+                    if (!m->is_array() || m->arr.size() != 9) r.fail("%s: \"matrix\" must be an array of 9 numbers", where);
+                    else {
+                        for (int k = 0; k < 9; ++k) {
+                            if (!m->arr[k].is_number()) r.fail("%s: \"matrix\" must be an array of 9 numbers", where);
+                            M[k] = (float)m->arr[k].num;
+                        }
+                        pm = M;
+                    }
+                }
+                if (o.find("translate")) {
+                    double d[3];
+                    r.vec3(o, "translate", where, d);
+                    T[0] = (float)d[0], T[1] = (float)d[1], T[2] = (float)d[2];
+                    pt = T;
+                }
+                if (r.ok) {
+                    const int rc = add_obj(s, resolve(f->str).c_str(), mat, scale, pm, pt);
+                    if (rc < 0) return -rc;
+                }
             } else {
                 r.fail("%s: unknown type \"%s\"", where, t.c_str());
             }
@@ -509,6 +812,17 @@ std::string scene_to_json(const Scene &s) {
             }
             break;
         }
+        case RT_PRIM_TRIANGLE: {
+            o += "{\"type\": \"triangle\"";
+            const char *vk[3] = {"v1", "v2", "v3"}, *uk[3] = {"u1", "u2", "u3"};
+            for (int c = 0; c < 3; ++c) {
+                o += std::string(", \"") + vk[c] + "\": ";
+                put_vec3(o, p.m + 3 * c);
+            }
+            for (int c = 0; c < 3; ++c)
+                o += std::string(", \"") + uk[c] + "\": [" + json_float(p.m_inv[2 * c]) + ", " + json_float(p.m_inv[2 * c + 1]) + "]";
+            break;
+        }
         default: break;
         }
         o += ", \"material\": " + std::to_string(p.material) + "}";
@@ -545,6 +859,16 @@ std::string scene_to_json(const Scene &s) {
             o += "{\"type\": \"solid_color\", \"color\": ";
             put_vec3(o, t.c0);
             o += "}";
+        } else if (t.type == RT_TEX_IMAGE) {
+            const SceneImage &im = s.images[(size_t)t.c0[0]];
+            if (!im.file.empty()) {
+                o += "{\"type\": \"image\", \"file\": " + json_escape(im.file) + "}";
+            } else {
+                o += "{\"type\": \"image\", \"rows\": " + std::to_string(im.rows) + ", \"cols\": " + std::to_string(im.cols) +
+                     ", \"data\": [";
+                for (size_t k = 0; k < im.rgb.size(); ++k) o += (k ? "," : "") + std::to_string((int)im.rgb[k]);
+                o += "]}";
+            }
         } else {
             o += "{\"type\": \"checker\", \"even\": ";
             put_vec3(o, t.c0);

@@ -29,6 +29,13 @@ struct CylinderXform {
     double offset[3] = {0, 0, 0};
 };
 
+// pixels of an image texture (taichi-version/material.py:96-110): rows x cols texels, R G B bytes
+struct SceneImage {
+    int rows = 0, cols = 0;
+    std::vector<uint8_t> rgb;
+    std::string file;  // where it was read from ("" = given inline), for serialisation
+};
+
 struct DeviceSceneCache;  // owned by the render module
 
 struct Scene {
@@ -42,6 +49,7 @@ struct Scene {
     std::vector<CylinderXform> xforms;  // parallel to prims (meaningful for cylinders)
     std::vector<rt_material> mats;
     std::vector<rt_texture> texs;
+    std::vector<SceneImage> images;  // referenced by RT_TEX_IMAGE textures (c0[0] = index)
     uint64_t version = 1;  // bumped on every mutation; invalidates device caches
     std::shared_ptr<DeviceSceneCache> dev;
 
@@ -52,13 +60,21 @@ struct Scene {
 void derive_camera(const Scene &s, rt_camera *out);
 
 // all return RT_OK or an rt_status, message via set_error()
-int scene_from_json(const char *text, size_t len, Scene &out);
+// base_dir: directory that relative "file" entries (image textures, meshes) are resolved against (NULL: the cwd)
+int scene_from_json(const char *text, size_t len, Scene &out, const char *base_dir = nullptr);
 std::string scene_to_json(const Scene &s);
 void scene_rtiow(Scene &out, uint32_t seed, int width, int height, int spp, int max_depth);
 int scene_validate(const Scene &s);
 
 int add_cylinder(Scene &s, float radius, float zmin, float zmax, int material, const double *axis,
                  double degrees, const double *offset);
+
+// -> texture id / triangles added / prim id, or -rt_status
+int add_image_texture(Scene &s, int rows, int cols, const uint8_t *rgb, const std::string &file);
+int add_image_texture_file(Scene &s, const char *path);
+int add_triangle(Scene &s, const float v1[3], const float v2[3], const float v3[3], const float uv1[2], const float uv2[2],
+                 const float uv3[2], int material);
+int add_obj(Scene &s, const char *path, int material, float scale, const float matrix[9], const float translate[3]);
 
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 const char *get_error();

@@ -31,12 +31,17 @@ class _RtoCameraParams(C.Structure):
                 ("vfov", C.c_double), ("aspect", C.c_double), ("aperture", C.c_double), ("focus_dist", C.c_double)]
 
 
+class _RtoImage(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("rgb", C.c_void_p)]
+
+
 class _RtoScene(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32), ("flags", C.c_uint32),
                 ("background", C.c_float * 3), ("cam", _RtoCamera),
                 ("prims", C.c_void_p), ("num_prims", C.c_int32),
                 ("mats", C.c_void_p), ("num_mats", C.c_int32),
-                ("texs", C.c_void_p), ("num_texs", C.c_int32), ("rr_p", C.c_float)]
+                ("texs", C.c_void_p), ("num_texs", C.c_int32), ("rr_p", C.c_float),
+                ("images", C.c_void_p), ("num_images", C.c_int32)]
 
 
 class _RtoCounts(C.Structure):
@@ -137,6 +142,16 @@ class OracleScene:
         s.mats, s.num_mats = self.mats.ctypes.data, len(self.mats)
         s.texs, s.num_texs = self.texs.ctypes.data, len(self.texs)
         s.rr_p = info.russian_roulette
+        # pixels of the image textures (texture record: c0 = {image index, rows, cols})
+        self.images = {}
+        for ti, t in enumerate(self.texs):
+            if t["type"] == 2:
+                self.images[int(t["c0"][0])] = np.ascontiguousarray(scene.get_image(ti))
+        n_img = (max(self.images) + 1) if self.images else 0
+        self.image_recs = (_RtoImage * max(1, n_img))()
+        for k, px in self.images.items():
+            self.image_recs[k].rows, self.image_recs[k].cols, self.image_recs[k].rgb = px.shape[0], px.shape[1], px.ctypes.data
+        s.images, s.num_images = C.cast(self.image_recs, C.c_void_p), n_img
         self.c = s
         self.width, self.height, self.spp = info.width, info.height, info.samples_per_pixel
 
@@ -165,6 +180,19 @@ def oracle_render_rect(scene, seed, x0, x1, y0, y1, sample_first=0, sample_count
     rc = lib.rto_render_rect(C.byref(osc.c), seed, x0, x1, y0, y1, sample_first, n, out.ctypes.data, None, threads)
     assert rc == 0
     return out[y0:y1, x0:x1].copy()
+
+
+def oracle_hit_uv(scene, origin, direction):
+    """Closest hit of one ray in the checker: (hit?, (u, v), t, prim index) -- the hit record's texture coordinates."""
+    lib = oracle_lib()
+    osc = scene if isinstance(scene, OracleScene) else OracleScene(scene)
+    lib.rto_hit_uv.restype = C.c_int
+    lib.rto_hit_uv.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                               C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    o, d = (C.c_float * 3)(*origin), (C.c_float * 3)(*direction)
+    uv, t, prim = (C.c_float * 2)(), C.c_float(), C.c_int()
+    hit = lib.rto_hit_uv(C.cast(C.byref(osc.c), C.c_void_p), o, d, uv, C.byref(t), C.byref(prim))
+    return bool(hit), (uv[0], uv[1]), t.value, prim.value
 
 
 def oracle_sample(scene, seed, x, y, sample):
