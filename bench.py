@@ -61,8 +61,7 @@ F_SCATTER = [40, 55, 65, 0]  # lambertian, metal, dielectric, diffuse_light
 F_MISS = 25            # sky / background evaluation
 F_BOX = 12             # slab test of one box: 6 fma (the min/max/compare that follow count 0)
 F_CULL_SETUP = 17      # per query: 3 reciprocals, margin (mul + add), 6 shifted origins (add + mul each)
-F_GRID_SETUP = 26      # per query of the grid walk: the above + entry point and per-axis step set-up (3 fma + 6 mul)
-F_GRID_STEP = 4        # per visited cell: one add on the stepped axis + the cell address (fma) -- the rest is compares
+F_RANGE_LOOKUP = 24    # per window box a ray reaches: 6 fma for the clipped segment's end points, 2 axes x (2 margin + 2 offset + 2 scale)
 
 
 def algorithmic_flops(counts: dict, prim_types) -> float:
@@ -292,7 +291,8 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
         shading = linear_flops - per_query_linear * c["queries"]  # 46 S + 30 H + scatter + 25 M
         flops_strict = 17 * sphere_tests + n_other * c["queries"] + shading            # box tests = accelerator overhead
         flops = flops_strict + F_BOX * box_tests + setup
-        roof["mode"] = ("culled hittable_list (default kernel)" if culled else "linear hittable_list scan (variant 16)")
+        roof["mode"] = ("culled hittable_list: candidate clusters from range tables, per-lane cluster lists (default kernel)"
+                        if culled else "linear hittable_list scan (variant 16)")
         if args.variant in (8, 32):  # the diagnostic kernel is the default one: its counts do not describe these
             roof["mode"] = "ablation variant with wave-level cluster votes: no flop count"
             flops = flops_strict = 0
@@ -307,7 +307,7 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
                               "frac_excluding_box_tests counts the accelerator's own work as 0")
         roof["counts"] = {k: c[k] for k in ("samples", "queries", "prim_tests", "hits", "misses", "scatter",
                                             "rng_draws", "wave_queries", "clusters_visited", "groups_visited",
-                                            "lane_clusters", "lane_groups") if k in c}
+                                            "lane_clusters", "lane_groups", "lane_cands") if k in c}
         roof["tests_per_sample"] = {"sphere": round(sphere_tests / max(1, c["samples"]), 1),
                                     "box": round(box_tests / max(1, c["samples"]), 1),
                                     "reference_linear_scan": round(c["prim_tests"] / max(1, c["samples"]), 1)}
@@ -345,13 +345,14 @@ def executed_tests(c: dict, lanes: float):
     """Ray-primitive and box tests the default kernel's lanes execute, from the diagnostic counters.
     Returns (sphere tests, box tests, per-query set-up flops)."""
     q = c["queries"]
-    if c.get("grid_cells", 0) or c.get("cull_grid", 0):
-        # grid walk: prefix spheres for every query, one scene-box test per query, then per visited cell its spheres
-        sphere_tests = q * c["cull_prefix"] + c["grid_tests"]
-        box_tests = q  # the grid's bounding box
-        setup = F_GRID_SETUP * q + F_GRID_STEP * c["grid_cells"]
-        return sphere_tests, box_tests, setup
-    # cluster boxes: every live lane tests the always-tested prefix, every outer box, the cluster boxes of the outer
+    if c.get("cull_mode", 2) == 3:
+        # range tables: every live lane tests the always-tested prefix and clips its ray against every window box;
+        # where it reaches one it looks its candidate clusters up (segment end points + slab indices: 24 flops),
+        # tests the box of every candidate and the spheres of the clusters ITS OWN ray reaches
+        sphere_tests = q * c["cull_prefix"] + c["lane_clusters"] * c["cull_cluster_size"]
+        box_tests = q * c["cull_windows"] + c["lane_cands"]
+        return sphere_tests, box_tests, F_CULL_SETUP * q + F_RANGE_LOOKUP * c["lane_groups"]
+    # box hierarchy: every live lane tests the always-tested prefix, every outer box, the cluster boxes of the outer
     # boxes some lane of its wave passed, and the spheres of the clusters ITS OWN ray reaches
     sphere_tests = q * c["cull_prefix"] + c["lane_clusters"] * c["cull_cluster_size"]
     box_tests = q * c["cull_groups"] + lanes * c["groups_visited"] * 4

@@ -266,11 +266,13 @@ typedef struct rt_stats {
     uint64_t scatter[4];  /* per rt_mat_type */
     uint64_t rng_draws;
     uint64_t cand_lanes, cand_waves; /* sphere candidates that reached the sqrt block: lanes / wave entries */
-    uint64_t clusters_visited;       /* culling: sphere clusters a wave actually tested */
+    uint64_t clusters_visited;       /* culling: rounds of the per-lane cluster walk, per wave (= clusters a wave tested
+                                        when it votes as a whole) */
     uint64_t wave_queries;           /* closest-hit queries executed, counted per WAVE */
-    uint64_t groups_visited;         /* culling: outer boxes that passed, per wave */
+    uint64_t groups_visited;         /* culling: outer boxes that passed, per wave; range tables: rounds of the per-lane
+                                        candidate box tests, per wave */
     uint64_t lane_clusters;          /* culling: cluster boxes that passed, per LANE (what each ray needs) */
-    uint64_t lane_groups;            /* culling: outer boxes that passed, per LANE */
+    uint64_t lane_groups;            /* culling: outer boxes that passed, per LANE; range tables: window boxes reached */
     uint64_t group_maxpop;           /* culling: max over lanes of needed clusters, summed over visited groups */
     uint64_t query_maxpop;           /* culling: max over lanes of needed clusters, summed over wave-queries */
     uint64_t cycles[6];              /* shader-clock time per main-loop section, summed over waves: refill, prefix
@@ -280,6 +282,9 @@ typedef struct rt_stats {
                                         to last exit (s_memrealtime) */
     /* rt_render_hip_tiles only: kernel_ms above is the SLOWEST device's render launches */
     uint64_t lane_cands;  /* culling by range tables: candidate clusters per LANE before the per-cluster box test */
+    int32_t cull_mode;    /* candidate search of the kernel that ran: 3 range tables, 2 box hierarchy per lane, 1 wave
+                             votes, 0 none (flat scan) */
+    int32_t cull_windows; /* windows of 64 clusters */
     double gather_ms;     /* root device: end of its own render -> assembled frame (ncclGather + row placement,
                              includes waiting for slower peers) */
     int32_t devices_used;

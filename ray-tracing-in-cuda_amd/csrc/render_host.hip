@@ -140,16 +140,13 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     // (RTIOW's small spheres on the ground: the centres' bound is flat) fall into square blocks of 16 = 4 x 4
     // rather than 2 x 4 (230 vs 237 ms); spheres filling a volume into cubes of 8 = 2 x 2 x 2 rather than
     // 2 x 2 x 4 (random clouds 20 %, the DNA scene 6 % faster with 8).  RTMI_CLUSTER=8|16 overrides.
+    // Spheres per cluster.  8 everywhere: with the candidate clusters looked up in the range tables, the per-cluster
+    // box tests no longer pay for themselves by being few (RTIOW: 53.5 ms with 8 against 55.4 ms with 16 per 256 spp;
+    // the box hierarchy of round 1 preferred 4 x 4 blocks of 16 on sheet-like scenes).  RTMI_CLUSTER=16 keeps the
+    // other build reachable for measurements.
     int csize = 8;
     if (const char *e = getenv("RTMI_CLUSTER")) {
         if (atoi(e) == 16) csize = 16;
-    } else if (rest.size() > 32) {
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int i : rest)
-            for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], s.prims[i].f[a]), hi[a] = std::max(hi[a], s.prims[i].f[a]);
-        float ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
-        std::sort(ext, ext + 3);
-        if (ext[1] > 0.0f && ext[0] < 0.1f * ext[1]) csize = 16;  // a sheet, not a volume
     }
     // Cluster q occupies the slots [np + q (csize + 1), + csize) followed by ONE never-hit slot: with a stride of
     // csize + 1 records, record h of clusters q and q' lies (q - q') records apart modulo 16, so the lanes of a wave
@@ -884,6 +881,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->wave_queries = h.wave_queries;
             stats->cull_prefix = P.np, stats->cull_clusters = P.ncl, stats->cull_groups = P.ngr;
             stats->cull_cluster_size = P.cluster;
+            stats->cull_mode = variant_cull_mode(variant), stats->cull_windows = P.nwin;
         }
     }
     return RT_OK;

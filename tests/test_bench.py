@@ -49,6 +49,11 @@ def test_flop_accounting_follows_survey_8d():
          "groups_visited": 30}
     s, bx, setup = b.executed_tests(c, lanes=64.0)
     assert s == 640 * 4 + 1000 * 16 and bx == 640 * 8 + 64 * 30 * 4 and setup == b.F_CULL_SETUP * 640
+    # range tables (the default): one window-box clip per query and window, one box test per candidate cluster
+    c = {"queries": 640, "cull_prefix": 4, "lane_clusters": 1200, "cull_cluster_size": 8, "cull_mode": 3, "cull_windows": 1,
+         "lane_cands": 2000, "lane_groups": 470}
+    s, bx, setup = b.executed_tests(c, lanes=64.0)
+    assert s == 640 * 4 + 1200 * 8 and bx == 640 + 2000 and setup == b.F_CULL_SETUP * 640 + b.F_RANGE_LOOKUP * 470
 
 
 def test_cpu_baseline_leg_runs_on_all_cores(rtmi):

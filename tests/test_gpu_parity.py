@@ -320,17 +320,17 @@ def test_axis_parallel_bounce_is_not_culled(rtmi, rtcheck):
 
 
 def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
-    """The packer clusters spheres on a sheet by 16 and spheres in a volume by 8 (both kernels are compiled);
-    RTMI_CLUSTER forces the other choice, which must not change a bit."""
+    """The packer clusters spheres by 8 (both kernels are compiled; round 1's box hierarchy preferred 16 on sheets);
+    RTMI_CLUSTER forces either size, which must not change a bit."""
     for forced in ("8", "16"):
         monkeypatch.setenv("RTMI_CLUSTER", forced)
-        sc = rtmi.Scene.rtiow(5, 120, 68, 5, 50)   # a sheet: 16 by default
+        sc = rtmi.Scene.rtiow(5, 120, 68, 5, 50)   # a sheet
         st = sc.count(rtmi.Opts(seed=SEED))
         assert st.cull_cluster_size == int(forced)
         _assert_same(rtmi, rtcheck, sc)
         _assert_same(rtmi, rtcheck, sc, variant=32)
         _assert_same(rtmi, rtcheck, sc, variant=64)
-        vol = rtmi.Scene.new(64, 40, 3, 10)        # a volume: 8 by default
+        vol = rtmi.Scene.new(64, 40, 3, 10)        # a volume
         vol.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
         vol.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
         rng = np.random.default_rng(21)
@@ -342,7 +342,7 @@ def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
         _assert_same(rtmi, rtcheck, vol, variant=40)
         _assert_same(rtmi, rtcheck, vol, variant=104)
     monkeypatch.delenv("RTMI_CLUSTER")
-    assert rtmi.Scene.rtiow(5, 32, 18, 1, 5).count(rtmi.Opts()).cull_cluster_size == 16
+    assert rtmi.Scene.rtiow(5, 32, 18, 1, 5).count(rtmi.Opts()).cull_cluster_size == 8
     vol2 = rtmi.Scene.new(16, 16, 1, 3)
     vol2.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
     m = vol2.lambertian((0.5, 0.5, 0.5))
@@ -370,8 +370,9 @@ def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
     st = sc.count(rtmi.Opts(seed=SEED))
     # the culled kernel really skips work: far fewer clusters visited than waves x clusters
     assert 0 < st.clusters_visited < 0.35 * st.wave_queries * st.cull_clusters
-    # RTIOW's small spheres lie on a sheet: the packer picks 16 per cluster (480 spheres -> 30 clusters)
-    assert st.cull_prefix == 4 and st.cull_cluster_size == 16 and st.cull_clusters == 30
+    # 4 big spheres are always tested; the 480 small ones make 60 clusters of 8 = one 64-cluster window
+    assert st.cull_prefix == 4 and st.cull_cluster_size == 8 and st.cull_clusters == 60
+    assert st.cull_mode == 3 and st.cull_windows == 1 and 0 < st.lane_clusters <= st.lane_cands
     # a second scene seed, and the DNA frame (30 cylinders culled by their world-space boxes)
     sc2 = rtmi.Scene.rtiow(11, 960, 540, 16, 50)
     assert np.array_equal(sc2.render(rtmi.Opts(seed=3)), sc2.render(rtmi.Opts(seed=3, variant=16)))
