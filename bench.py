@@ -317,7 +317,7 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
     # 64-bit accumulator plane (clear, one flush per work item, read-back)
     rows0 = scene.shard_rows(mine)
     plane = rows0 * scene.width * 3
-    n_chunks = -(-scene.spp // (chunk or 64))
+    n_chunks = -(-scene.spp // (chunk or 128))  # 0 = the library default, 128 samples per work item
     algo_bytes = plane * (8 + 8 * n_chunks + 8 + 4)
     roof["hbm_survey_bytes"] = int(rows0 * scene.width * 16)
     roof["hbm_algorithmic_bytes"] = int(algo_bytes)

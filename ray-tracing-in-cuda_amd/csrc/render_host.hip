@@ -566,14 +566,15 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
 
     int sample_first = o ? o->sample_first : 0;
     int sample_count = (o && o->sample_count > 0) ? o->sample_count : s.spp;
-    // samples per work item: scheduling only (the pixel sum is exact).  64 measured best on MI355X for
-    // frames that fill the chip; small frames get smaller chunks so that there are a few items per
+    // samples per work item: scheduling only (the pixel sum is exact).  64 and 128 measure the same on MI355X for
+    // frames that fill the chip (199.8 / 200.2 ms; 256: 204.3) and 128 halves the accumulator traffic -- one 1.5 KB
+    // tile flush and a handful of orphaned paths per item; small frames get smaller chunks so that there are a few items per
     // resident wave (a 400x225 frame has 1450 tiles for ~6000 resident waves)
     int spp_chunk = (o && o->spp_chunk > 0) ? o->spp_chunk : 0;
     if (spp_chunk == 0) {
         const long long tiles = (long long)((s.width + 7) / 8) * ((sh.local_rows + 7) / 8);
         const long long want_items = 4LL * 256 * RT_WAVES_PER_SIMD * 4;  // 4 items per resident wave
-        spp_chunk = 64;
+        spp_chunk = 128;
         while (spp_chunk > 8 && tiles * ((sample_count + spp_chunk - 1) / spp_chunk) < want_items) spp_chunk /= 2;
     }
     if (spp_chunk > sample_count) spp_chunk = sample_count;

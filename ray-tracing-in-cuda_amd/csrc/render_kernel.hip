@@ -54,7 +54,7 @@
 // the flat-scan ablation kernels (CULL == 0) keep two register sets of sphere records in flight
 // an item is retired (its LDS accumulator flushed and reused) once at most this many of its paths are still alive
 #ifndef RT_ORPHAN_MAX
-#define RT_ORPHAN_MAX 16
+#define RT_ORPHAN_MAX 12
 #endif
 // MEASUREMENT ONLY (wrong images; never defined by the Makefile): what a section costs is what the frame gains when it
 // is cut out -- RT_ABLATE=1 rejection loops accept their first candidate, 2 no pixel accumulation, 4 the sample
@@ -431,26 +431,36 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             // would give inf, and the fma form below inf - inf = NaN on the face behind the origin, which
             // min/max then drop together with the slab.  With a huge finite value the axis keeps its
             // meaning: origin inside the slab -> (-huge, +huge), outside -> both of one sign -> dead.
-            const float idx = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dx), -1e18f, 1e18f);
-            const float idy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dy), -1e18f, 1e18f);
-            const float idz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dz), -1e18f, 1e18f);
-            // per-lane box margin covering the fp32 error of the sphere test at this origin's
-            // distance (derivation in render_host.hip): two shifted origins, nothing per box
-            const float marg = 4e-3f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + P.cull_extent1);
-            // slab distances as one fma per face: t = b * (1/d) - (o +- marg) * (1/d).  The products
-            // cancel to an absolute error ~ eps |o/d|, i.e. ~1e-7 |o| in space: four orders of
-            // magnitude inside the margin.
-            const float nxm = -(ox + marg) * idx, nym = -(oy + marg) * idy, nzm = -(oz + marg) * idz;
-            const float nxp = -(ox - marg) * idx, nyp = -(oy - marg) * idy, nzp = -(oz - marg) * idz;
+            // The values are only needed around the box tests; they are derived where those sit (per window of
+            // clusters, and once more for the cylinders' and triangles' boxes) instead of once per query, so that
+            // the ten registers are free while the wave walks its clusters -- the kernel's register peak.
+            struct BoxP {
+                float idx, idy, idz, nxm, nym, nzm, nxp, nyp, nzp, marg;
+            };
+            auto box_params = [&]() -> BoxP {
+                BoxP b;
+                b.idx = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dx), -1e18f, 1e18f);
+                b.idy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dy), -1e18f, 1e18f);
+                b.idz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(dz), -1e18f, 1e18f);
+                // per-lane box margin covering the fp32 error of the sphere test at this origin's
+                // distance (derivation in render_host.hip): two shifted origins, nothing per box
+                b.marg = 4e-3f * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + P.cull_extent1);
+                // slab distances as one fma per face: t = b * (1/d) - (o +- marg) * (1/d).  The products
+                // cancel to an absolute error ~ eps |o/d|, i.e. ~1e-7 |o| in space: four orders of
+                // magnitude inside the margin.
+                b.nxm = -(ox + b.marg) * b.idx, b.nym = -(oy + b.marg) * b.idy, b.nzm = -(oz + b.marg) * b.idz;
+                b.nxp = -(ox - b.marg) * b.idx, b.nyp = -(oy - b.marg) * b.idy, b.nzp = -(oz - b.marg) * b.idz;
+                return b;
+            };
             const float4 *box = hot + P.off_box;
             const float4 *gbox = hot + P.off_gbox;
             // best_t (1 + 1e-4), refreshed whenever spheres have been tested (a stale, larger value only
             // culls less)
             float blim = best_t * 1.0001f;
-            auto slab_live = [&](const float4 bmn, const float4 bmx) -> bool {
-                const float lx = fmaf(bmn.x, idx, nxm), ux = fmaf(bmx.x, idx, nxp);
-                const float ly = fmaf(bmn.y, idy, nym), uy = fmaf(bmx.y, idy, nyp);
-                const float lz = fmaf(bmn.z, idz, nzm), uz = fmaf(bmx.z, idz, nzp);
+            auto slab_live = [&](const BoxP &b, const float4 bmn, const float4 bmx) -> bool {
+                const float lx = fmaf(bmn.x, b.idx, b.nxm), ux = fmaf(bmx.x, b.idx, b.nxp);
+                const float ly = fmaf(bmn.y, b.idy, b.nym), uy = fmaf(bmx.y, b.idy, b.nyp);
+                const float lz = fmaf(bmn.z, b.idz, b.nzm), uz = fmaf(bmx.z, b.idz, b.nzp);
                 // live  <=>  tn <= tf, tf >= 0, tn <= best_t (1 + 1e-4)
                 //       <=>  max(tn, 0) <= min(tf, best_t (1 + 1e-4))          (NaN -> live)
                 const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
@@ -461,12 +471,14 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 // windows of 64 clusters: one mask bit per cluster
                 for (int w0 = 0; w0 < P.nwin; ++w0) {
                     // clip the ray to the window box (the union of its cluster boxes; same margin as every box test)
+                    const BoxP bp = box_params();
+                    const float idx = bp.idx, idy = bp.idy, idz = bp.idz, marg = bp.marg;
                     const float4 *wb = hot + P.off_wbox + 2 * w0;
                     const float4 wmn = wb[0], wmx = wb[1];
                     blim = best_t * 1.0001f;  // what the prefix and the previous windows found
-                    const float lx = fmaf(wmn.x, idx, nxm), ux = fmaf(wmx.x, idx, nxp);
-                    const float ly = fmaf(wmn.y, idy, nym), uy = fmaf(wmx.y, idy, nyp);
-                    const float lz = fmaf(wmn.z, idz, nzm), uz = fmaf(wmx.z, idz, nzp);
+                    const float lx = fmaf(wmn.x, idx, bp.nxm), ux = fmaf(wmx.x, idx, bp.nxp);
+                    const float ly = fmaf(wmn.y, idy, bp.nym), uy = fmaf(wmx.y, idy, bp.nyp);
+                    const float lz = fmaf(wmn.z, idz, bp.nzm), uz = fmaf(wmx.z, idz, bp.nzp);
                     const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
                     const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), blim), fmaxf(lz, uz));
                     const bool wlive = !(tn > tf);
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                             const int q = (int)__builtin_ctzll(cand);
                             cand ^= low;
                             const float4 *b = box + 2 * (w0 * 64 + q);
-                            if (slab_live(b[0], b[1])) mine |= low;
+                            if (slab_live(bp, b[0], b[1])) mine |= low;
                         }
                         if (COUNT) c_groups++;
                     }
@@ -546,19 +558,20 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 }
                 blim = best_t * 1.0001f;
             } else if (CULL == 2) {
+                const BoxP bp = box_params();
                 // windows of 64 clusters (16 outer boxes): one mask bit per cluster
                 for (int g0 = 0; g0 < P.ngr; g0 += 64 / RT_GROUP) {
                     // big scenes: one box around the whole window first (third level of the hierarchy)
                     if (P.nwin > 1) {
                         const float4 *wb = hot + P.off_wbox + 2 * (g0 / (64 / RT_GROUP));
-                        if (__builtin_amdgcn_ballot_w64(slab_live(wb[0], wb[1])) == 0ull) continue;
+                        if (__builtin_amdgcn_ballot_w64(slab_live(bp, wb[0], wb[1])) == 0ull) continue;
                         blim = best_t * 1.0001f;  // what the previous windows found tightens this one
                     }
                     // phase 1: which clusters can this lane's ray reach?  (wave-uniform box reads)
                     unsigned long long mine = 0ull;
                     const int g_end = min(P.ngr, g0 + 64 / RT_GROUP);
                     for (int g = g0; g < g_end; ++g) {
-                        const bool glive = slab_live(gbox[2 * g], gbox[2 * g + 1]);
+                        const bool glive = slab_live(bp, gbox[2 * g], gbox[2 * g + 1]);
                         if (__builtin_amdgcn_ballot_w64(glive) == 0ull) continue;
                         if (COUNT) c_groups++, c_lane_groups += glive ? 1u : 0u;
                         const int nj = min(RT_GROUP, P.ncl - g * RT_GROUP);
@@ -567,7 +580,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         for (int j = 0; j < RT_GROUP; ++j) {
                             if (j < nj) {
                                 const int q = g * RT_GROUP + j;
-                                if (slab_live(box[2 * q], box[2 * q + 1])) gm |= 1u << j;
+                                if (slab_live(bp, box[2 * q], box[2 * q + 1])) gm |= 1u << j;
                             }
                         }
                         if (COUNT) c_lane_clusters += __popc(gm);
@@ -600,13 +613,14 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 }
                 blim = best_t * 1.0001f;
             } else if (CULL == 1) {
+                const BoxP bp = box_params();
                 for (int g = 0; g < P.ngr; ++g) {
-                const bool glive = slab_live(gbox[2 * g], gbox[2 * g + 1]);
+                const bool glive = slab_live(bp, gbox[2 * g], gbox[2 * g + 1]);
                 if (__builtin_amdgcn_ballot_w64(glive) == 0ull) continue;
                 if (COUNT) c_groups++, c_lane_groups += glive ? 1u : 0u;
                 const int q_end = min(P.ncl, (g + 1) * RT_GROUP);
                 for (int q = g * RT_GROUP; q < q_end; ++q) {
-                    const bool live = slab_live(box[2 * q], box[2 * q + 1]);
+                    const bool live = slab_live(bp, box[2 * q], box[2 * q + 1]);
                     if (COUNT && live) c_lane_clusters++;
                     if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
                         const int base = P.np + (CSIZE + 1) * q;
@@ -650,13 +664,16 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 }
             }
 
+            // the boxes of cylinders and triangles: the box-test values once more (see box_params)
+            BoxP bq = {};
+            if (CULL && (nc > 0 || (EXT && nt > 0))) bq = box_params();
             // cylinders: cylinder::hit + quadratic, object.cuh:199-214, 233-290
             for (int k = 0; k < nc; ++k) {
                 if (CULL) {
                     blim = best_t * 1.0001f;  // the cylinder's world-space box, same margin (the object-space quadratic has the
                              // same error structure as the sphere test: ~1e-3 |o| in space)
                     const float4 *cb = hot + P.off_cbox + 2 * k;
-                    if (__builtin_amdgcn_ballot_w64(slab_live(cb[0], cb[1])) == 0ull) continue;
+                    if (__builtin_amdgcn_ballot_w64(slab_live(bq, cb[0], cb[1])) == 0ull) continue;
                 }
                 const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2], pr = cyl[4 * k + 3];
                 const float oox = fmaf(r0.x, ox, fmaf(r0.y, oy, fmaf(r0.z, oz, r0.w)));
@@ -715,7 +732,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 if (CULL) {
                     blim = best_t * 1.0001f;
                     const float4 *tb = hot + P.off_tbox + 2 * k;
-                    if (__builtin_amdgcn_ballot_w64(slab_live(tb[0], tb[1])) == 0ull) continue;
+                    if (__builtin_amdgcn_ballot_w64(slab_live(bq, tb[0], tb[1])) == 0ull) continue;
                 }
                 const float4 r0 = tri[3 * k], r1 = tri[3 * k + 1], r2 = tri[3 * k + 2];
                 float rix, riy, riz, root;

@@ -1,14 +1,18 @@
 """Turn a tools/profile.sh output directory into the committed summary under profiles/."""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, subprocess, sys
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = {"tag": tag, "source": "rocprofv3 (ROCm 7.2) on MI355X via tools/profile.sh", "kernel_stats": [], "pmc": {}}
+try:
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    head = None
+out = {"tag": tag, "source": "rocprofv3 (ROCm 7.2) on MI355X via tools/profile.sh", "head": head, "kernel_stats": [], "pmc": {}}
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         out["kernel_stats"].append({k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Kernel_Name"]:
+        if "render_kernel<false, true, true, false, 3," in r["Kernel_Name"]:  # the default kernel
             out["render_dispatch"] = {k: r[k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")}
             break
 agg = collections.defaultdict(float); launches = collections.defaultdict(int)
@@ -29,6 +33,8 @@ if "GRBM_GUI_ACTIVE" in p and "SQ_INSTS_VALU" in p:
     d["kernel_cycles"] = cyc
     d["valu_busy"] = p["SQ_INSTS_VALU"] / 1024 * 2 / cyc   # wave64 VALU = 2 cycles on a SIMD-32, 1024 SIMDs
     if "SQ_WAVE_CYCLES" in p: d["avg_waves_per_simd"] = p["SQ_WAVE_CYCLES"] * 4 / (1024 * cyc)
+if "SQ_LDS_BANK_CONFLICT" in p and "SQ_LDS_IDX_ACTIVE" in p:
+    d["lds_bank_conflict_ratio"] = p["SQ_LDS_BANK_CONFLICT"] / p["SQ_LDS_IDX_ACTIVE"]
 if "SQ_WAVE_CYCLES" in p:
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in p: d[k.lower() + "_frac_of_wave_cycles"] = p[k] / p["SQ_WAVE_CYCLES"]
@@ -40,6 +46,7 @@ json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json"
 if "hbm_read_bytes_per_launch" in d and "hbm_write_bytes_per_launch" in d:
     tf = {"1920x1080x1024": {"bytes_per_launch": int(d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]),
                              "read_bytes": int(d["hbm_read_bytes_per_launch"]), "write_bytes": int(d["hbm_write_bytes_per_launch"]),
+                             "head": head,
                              "source": f"profiles/{tag}_rocprof_summary.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE, separate passes, render_kernel only"}}
     json.dump(tf, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out["derived"], indent=1)); print(out.get("render_dispatch")); 
