@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -49,12 +50,14 @@ struct DeviceEntry {
     unsigned long long *d_acc = nullptr;  // fixed-point pixel accumulators of the last launch
     size_t acc_bytes = 0;
     DevCounters *d_counters = nullptr;
+    float *d_out = nullptr;  // framebuffer of the host-buffer entry points (rt_render_hip), kept between calls
+    size_t out_bytes = 0;
     int num_cus = 0;
 };
 
 struct DeviceSceneCache {
-    std::mutex mu;
-    std::vector<DeviceEntry> entries;
+    std::mutex mu;  // guards the packed image and the entry list -- not the launches of an entry
+    std::vector<std::unique_ptr<DeviceEntry>> entries;  // stable addresses: one entry per device
     // host-side packed image (rebuilt when the scene version changes)
     uint64_t packed_version = 0;
     std::vector<float> image;  // float4 records
@@ -62,12 +65,14 @@ struct DeviceSceneCache {
     ~DeviceSceneCache() {
         int cur = 0;
         bool have = hipGetDevice(&cur) == hipSuccess;
-        for (DeviceEntry &e : entries) {
+        for (auto &ep : entries) {
+            DeviceEntry &e = *ep;
             if (e.device < 0) continue;
             if (hipSetDevice(e.device) != hipSuccess) continue;
             if (e.d_image) (void)hipFree(e.d_image);
             if (e.d_acc) (void)hipFree(e.d_acc);
             if (e.d_counters) (void)hipFree(e.d_counters);
+            if (e.d_out) (void)hipFree(e.d_out);
         }
         if (have) (void)hipSetDevice(cur);
     }
@@ -586,8 +591,8 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // frame (r = 0.22) gives up three of sixteen, a 1/8 row shard (r = 1.8) all sixteen, of which 22
     // quarter chunks are cut into 4-sample items.  Short items cost little since stragglers no longer
     // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
-    const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob: 0 = off
-    const double tail_factor = getenv("RTMI_TAIL_FACTOR") ? atof(getenv("RTMI_TAIL_FACTOR")) : 12.0;  // measured at 7 waves/SIMD: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms, a 1/8 shard 33.7 / 33.4 / 32.0 / 32.2 ms
+    static const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob, read once: 0 = off
+    static const double tail_factor = getenv("RTMI_TAIL_FACTOR") ? atof(getenv("RTMI_TAIL_FACTOR")) : 12.0;  // measured at 7 waves/SIMD: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms, a 1/8 shard 33.7 / 33.4 / 32.0 / 32.2 ms
     int n_big = sample_count / spp_chunk, n_med = 0, q_med = spp_chunk, q_small = spp_chunk;
     int num_chunks;
     {
@@ -663,14 +668,16 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     Scene &ms = const_cast<Scene &>(s);
     if (!ms.dev) ms.dev = std::make_shared<DeviceSceneCache>();
     DeviceSceneCache &cache = *ms.dev;
-    std::lock_guard<std::mutex> lock(cache.mu);
+    // The lock covers packing, the entry list and the enqueueing of this call's work; it is released before the
+    // call waits for the device (stats), so that threads which render one scene on DIFFERENT devices overlap.
+    std::unique_lock<std::mutex> lock(cache.mu);
     if (cache.packed_version != s.version) pack_scene(s, cache);
     DeviceEntry *ent = nullptr;
-    for (DeviceEntry &e : cache.entries)
-        if (e.device == device) ent = &e;
+    for (auto &e : cache.entries)
+        if (e->device == device) ent = e.get();
     if (!ent) {
-        cache.entries.emplace_back();
-        ent = &cache.entries.back();
+        cache.entries.emplace_back(new DeviceEntry());
+        ent = cache.entries.back().get();
         ent->device = device;
     }
     struct Events {  // destroyed on every return path
@@ -695,8 +702,9 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             HIP_TRY(hipMalloc(&ent->d_image, image_bytes));
             ent->image_bytes = image_bytes;
         }
-        // the image must be complete before any stream may read it; scenes are a few KB
-        HIP_TRY(hipMemcpy(ent->d_image, cache.image.data(), image_bytes, hipMemcpyHostToDevice));
+        // stream-ordered: the launches below follow on the same stream (renders of one scene object on one device share
+        // a stream: include/rtmi.h).  The source is pageable, so the call returns once the bytes are staged.
+        HIP_TRY(hipMemcpyAsync(ent->d_image, cache.image.data(), image_bytes, hipMemcpyHostToDevice, stream));
         ent->version = s.version;
     }
 
@@ -835,6 +843,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
 
     if (stats) {
         HIP_TRY(hipEventRecord(ev2, stream));
+        lock.unlock();
         HIP_TRY(hipEventSynchronize(ev2));
         float up = 0, k = 0;
         HIP_TRY(hipEventElapsedTime(&up, ev0, ev1));
@@ -865,7 +874,8 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->wave_start_spread_us = (double)(h.t_start_max - h.t_start_min) * 0.01;
             stats->wave_end_spread_us = (double)(h.t_end_max - h.t_end_min) * 0.01;
             stats->wave_span_us = (double)(h.t_end_max - h.t_start_min) * 0.01;
-            if (getenv("RTMI_DEBUG_DRAIN")) {
+            static const bool debug_drain = getenv("RTMI_DEBUG_DRAIN") != nullptr;
+            if (debug_drain) {
                 fprintf(stderr, "shader clock over the waves' lifetimes: %.0f MHz\n", h.life_ticks ? 100.0 * (double)h.life_cycles / (double)h.life_ticks : 0.0);
                 fprintf(stderr, "queue-empty seen over %.1f us; first exit %.1f us after the first queue-empty; drain histogram (50 us bins):",
                         (double)(h.t_qe_max - h.t_qe_min) * 0.01, (double)(h.t_end_min - h.t_qe_min) * 0.01);
@@ -924,9 +934,30 @@ static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_s
     HIP_TRY(hipGetDevice(&prev));
     if (prev != device) HIP_TRY(hipSetDevice(device));
     const size_t bytes = (size_t)sh.local_rows * sc->s.width * 3 * sizeof(float);
+    // the device framebuffer of this (scene, device) is kept between calls (no hipMalloc / hipFree per frame)
     float *d_out = nullptr;
     rt_stats local;
-    if (bytes && (rgb_sum || !h_acc)) HIP_TRY(hipMalloc((void **)&d_out, bytes));
+    if (bytes && (rgb_sum || !h_acc)) {
+        Scene &ms = const_cast<Scene &>(sc->s);
+        if (!ms.dev) ms.dev = std::make_shared<DeviceSceneCache>();
+        DeviceSceneCache &cache = *ms.dev;
+        std::lock_guard<std::mutex> lock(cache.mu);
+        DeviceEntry *ent = nullptr;
+        for (auto &e : cache.entries)
+            if (e->device == device) ent = e.get();
+        if (!ent) {
+            cache.entries.emplace_back(new DeviceEntry());
+            ent = cache.entries.back().get();
+            ent->device = device;
+        }
+        if (ent->out_bytes < bytes) {
+            if (ent->d_out) HIP_TRY(hipFree(ent->d_out));
+            ent->d_out = nullptr, ent->out_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&ent->d_out, bytes));
+            ent->out_bytes = bytes;
+        }
+        d_out = ent->d_out;
+    }
     rc = bytes ? render_impl(sc, o, d_out, nullptr, stats ? stats : &local, h_acc, count) : RT_OK;
     if (rc == RT_OK && rgb_sum && bytes) {
         hipError_t e = hipMemcpy(rgb_sum, d_out, bytes, hipMemcpyDeviceToHost);
@@ -935,7 +966,6 @@ static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_s
             rc = RT_ERR_HIP;
         }
     }
-    if (d_out) (void)hipFree(d_out);
     if (prev != device) (void)hipSetDevice(prev);
     return rc;
 }

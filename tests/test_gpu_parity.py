@@ -400,3 +400,14 @@ def test_bright_emitter_saturates_instead_of_wrapping(rtmi, rtcheck):
         sc.render(rtmi.Opts(sample_first=(1 << 23) - 5, sample_count=6))
     assert e.value.status == 6 and "samples per pixel" in str(e.value)
     assert sc.render(rtmi.Opts(sample_first=(1 << 23) - 6, sample_count=6)).shape == img.shape
+
+
+def test_unpinned_edge_cases_on_device(rtmi, rtcheck):
+    """The closed-form edge cases of the CUDA-only primitives (tests/test_primitives.py: cylinder far-root / end-cap
+    clipping / inside-wall normal flip, inclusive rect bounds, edge-on rects) rendered by the kernel: equal to the
+    checker bit for bit, and the expected values hold on the device too."""
+    import test_primitives as tp
+    for name, sc, want in tp.edge_case_scenes(rtmi):
+        img = _assert_same(rtmi, rtcheck, sc)
+        if want is not None:
+            assert np.all(img[4, 4] == np.float32(want) * sc.spp), name

@@ -155,3 +155,60 @@ def test_tie_rule_later_object_wins(rtmi, rtcheck):
             sc.xy_rect(-1, 1, -1, 1, 0.0, a)
             want = [1, 0, 0]
         assert np.all(_center_px(rtcheck, sc, 4) == np.float32(want))
+
+
+# ---- edge cases of the CUDA-only primitives (PARITY UNPINNED: no runnable reference; closed-form expectations) ----
+def edge_case_scenes(rtmi):
+    """(name, scene, expected centre-pixel radiance or None) -- also rendered on the device by
+    tests/test_gpu_parity.py::test_unpinned_edge_cases_on_device."""
+    out = []
+    # cylinder::hit, object.cuh:262-271: the near root t0 lies beyond the tube's zmax, so the hit is re-tried with the
+    # far root t1, which lies inside [zmin, zmax]: the ray enters through the open end and hits the INSIDE wall
+    # (front_face = false: the normal is flipped towards the ray, the emitter still emits)
+    sc = _probe_scene(rtmi, bg=(0, 0, 0), lookfrom=(0.0, 1.2, 6.0), lookat=(0.0, 0.0, 0.0), vfov=0.5)
+    sc.cylinder(0.5, -4.0, 1.0, sc.diffuse_light((3, 2, 1)))  # tube about z, open end at z = 1 facing the camera
+    out.append(("cylinder_far_root_inside_wall", sc, (3, 2, 1)))
+    # the same tube, but the far root is outside [zmin, zmax] as well: straight through both open ends -> background
+    sc = _probe_scene(rtmi, bg=(0.25, 0.5, 0.75), lookfrom=(0.0, 0.1, 6.0), lookat=(0.0, 0.0, 0.0), vfov=0.5)
+    sc.cylinder(0.5, -4.0, 1.0, sc.diffuse_light((3, 2, 1)))
+    out.append(("cylinder_through_both_ends", sc, (0.25, 0.5, 0.75)))
+    # t == t1 after the first root fails z: `if (t == t1) return false` -- origin inside the tube wall radius, looking
+    # out through the wall region beyond zmax: t0 < t_min, t = t1 is outside the z range -> miss
+    sc = _probe_scene(rtmi, bg=(0.25, 0.5, 0.75), lookfrom=(0.0, 0.0, 3.0), lookat=(1.0, 0.0, 3.0), vfov=0.5)
+    sc.cylinder(0.5, -1.0, 1.0, sc.diffuse_light((3, 2, 1)))
+    out.append(("cylinder_from_inside_beyond_the_end", sc, (0.25, 0.5, 0.75)))
+    # inside-tube normal flip with a scattering material: a mirror tube seen from inside reflects the ray back
+    # through the axis onto the opposite wall... until the depth runs out: exactly max_depth queries, black
+    sc = _probe_scene(rtmi, bg=(1, 1, 1), lookfrom=(0.0, 0.0, 0.0), lookat=(1.0, 0.0, 0.0), vfov=0.5, depth=7)
+    sc.cylinder(0.5, -1.0, 1.0, sc.metal((1, 1, 1), 0.0))
+    out.append(("mirror_tube_from_inside", sc, (0, 0, 0)))
+    # rect bounds are INCLUSIVE (object.cuh:112: `x < x0 || x > x1` rejects): a ray through the exact edge x = x1 hits
+    sc = _probe_scene(rtmi, bg=(0, 0, 0), lookfrom=(1.0, 0.0, 5.0), lookat=(1.0, 0.0, 0.0), vfov=1e-4)
+    sc.xy_rect(-1.0, 1.0, -1.0, 1.0, 0.0, sc.diffuse_light((2, 4, 8)))
+    out.append(("rect_edge_is_inside", sc, None))  # jitter moves half of the samples off the edge: checked per sample
+    # a rect seen exactly edge-on (ray parallel to its plane, origin off the plane): t = +-inf -> rejected
+    sc = _probe_scene(rtmi, bg=(0.25, 0.5, 0.75), lookfrom=(0.0, 0.5, 5.0), lookat=(0.0, 0.5, 0.0), vfov=1e-4)
+    sc.xz_rect(-1.0, 1.0, -10.0, 10.0, 0.0, sc.diffuse_light((2, 4, 8)))
+    out.append(("rect_edge_on", sc, (0.25, 0.5, 0.75)))
+    return out
+
+
+def test_unpinned_edge_cases(rtmi, rtcheck):
+    for name, sc, want in edge_case_scenes(rtmi):
+        vals = _center_px(rtcheck, sc, 32)
+        if want is not None:
+            assert np.all(vals == np.float32(want)), name
+        elif name == "rect_edge_is_inside":
+            # every sample is either the emitter (on or inside the edge) or the black background, and both occur
+            hit = np.all(vals == np.float32([2, 4, 8]), axis=1)
+            miss = np.all(vals == 0.0, axis=1)
+            assert np.all(hit | miss) and hit.any() and miss.any(), name
+    # the mirror tube really used its whole depth
+    sc = [s for n, s, _ in edge_case_scenes(rtmi) if n == "mirror_tube_from_inside"][0]
+    assert rtcheck.oracle_sample(sc, 5, 4, 4, 0)[1] == 7
+    # exact edge, no jitter: the ray (1, 0, 5) -> (0, 0, -1) meets x = x1 exactly and is a hit (inclusive bounds)
+    rect = _probe_scene(rtmi)
+    rect.xy_rect(-1.0, 1.0, -1.0, 1.0, 0.0, rect.lambertian((0.5, 0.5, 0.5)))
+    assert rtcheck.oracle_hit_uv(rect, (1.0, 0.0, 5.0), (0.0, 0.0, -1.0))[0]
+    assert rtcheck.oracle_hit_uv(rect, (1.0, -1.0, 5.0), (0.0, 0.0, -1.0))[0]      # the corner too
+    assert not rtcheck.oracle_hit_uv(rect, (np.nextafter(np.float32(1.0), np.float32(2.0)), 0.0, 5.0), (0.0, 0.0, -1.0))[0]
