@@ -735,6 +735,15 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     size_t hot_bytes = hot_bytes_of(variant);
     static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
                                                                              : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;
+    // The default candidate search is chosen per scene.  The range tables give the clusters a ray segment's BOUNDING BOX
+    // touches: sharp where the clustered spheres lie on a sheet (RTIOW: segments inside the sphere layer are short;
+    // 53.5 against 62.0 ms per 256 spp) or are few, blunt where they fill a volume -- a ray crosses the whole cloud and
+    // its box covers most of it (4000 random spheres: 27.8 against 20 ms).  Volumes keep the box hierarchy (bit 6).
+    {
+        const int n_axes = (P.rt_axes & 1) + ((P.rt_axes >> 1) & 1) + ((P.rt_axes >> 2) & 1);
+        if (variant == 0 && n_axes == 3 && P.ncl > 16 && !ext) variant = 64;  // (the EXT builds are range-table kernels)
+    }
+    hot_bytes = hot_bytes_of(variant);
     if (variant == 0 && hot_bytes > global_threshold) variant = 40;
     if (variant == 64 && hot_bytes > global_threshold) variant = 104;
     hot_bytes = hot_bytes_of(variant);

@@ -1263,6 +1263,7 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
     RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<true, true, true, SCALAR, CULL, 8>), g, t, lds_bytes, stream, P, img, acc, queue, counters),  \
                   hipLaunchKernelGGL((render_kernel<true, true, true, SCALAR, CULL, 16>), g, t, lds_bytes, stream, P, img, acc, queue, counters))
         if (variant == 40) { RT_COUNT_LAUNCH(true, 3) }
+        else if (variant == 104) { RT_COUNT_LAUNCH(true, 2) }
         else if (variant == 64) { RT_COUNT_LAUNCH(false, 2) }
         else { RT_COUNT_LAUNCH(false, 3) }
 #undef RT_COUNT_LAUNCH
@@ -1312,6 +1313,7 @@ int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster, b
     RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 8>, 256, lds_bytes),   \
                   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 16>, 256, lds_bytes))
         if (variant == 40) { RT_COUNT_OCC(true, 3) }
+        else if (variant == 104) { RT_COUNT_OCC(true, 2) }
         else if (variant == 64) { RT_COUNT_OCC(false, 2) }
         else { RT_COUNT_OCC(false, 3) }
 #undef RT_COUNT_OCC
