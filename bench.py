@@ -345,6 +345,10 @@ def executed_tests(c: dict, lanes: float):
     """Ray-primitive and box tests the default kernel's lanes execute, from the diagnostic counters.
     Returns (sphere tests, box tests, per-query set-up flops)."""
     q = c["queries"]
+    if c.get("cull_mode", 2) == 4:
+        # work-balanced ablation: no per-cluster box tests; every candidate cluster's spheres are tested (by some lane)
+        return (q * c["cull_prefix"] + c["lane_clusters"] * c["cull_cluster_size"], q * c["cull_windows"],
+                F_CULL_SETUP * q + F_RANGE_LOOKUP * c["lane_groups"])
     if c.get("cull_mode", 2) == 3:
         # range tables: every live lane tests the always-tested prefix and clips its ray against every window box;
         # where it reaches one it looks its candidate clusters up (segment end points + slab indices: 24 flops),

@@ -11,9 +11,9 @@
 //     tri     [nt]  3 x float4   {v1.xyz, n.x} {v2.xyz, n.y} {v3.xyz, n.z}   (n = unit normal, hittable.py:104)
 //     tbox    [nt]  2 x float4   bounding box of each triangle (culling variant)
 //   COLD part (stays in global memory / L2; read once per bounce by the winning lane)
-//     sphere  [ns]  1 x float4   {1/r, material(bits), list index(bits), 0}
-//     rect    [nr]  1 x float4   {material(bits), list index(bits), 0, 0}
-//     cyl     [nc]  4 x float4   m rows 0..2, {material(bits), list index(bits), 0, 0}
+//     sphere  [ns]  1 x float4   {1/r, material(bits), list index(bits), material kind(bits)}
+//     rect    [nr]  1 x float4   {material(bits), list index(bits), material kind(bits), 0}
+//     cyl     [nc]  4 x float4   m rows 0..2, {material(bits), list index(bits), material kind(bits), 0}
 //     tri     [nt]  2 x float4   {material(bits), list index(bits), u1.x, u1.y} {u2.x, u2.y, u3.x, u3.y}
 //     mat     [nm]  3 x float4   {kind(bits), p0, p1, p2} {c0.xyz, p3} {c1.xyz, 0}
 //     image   texels of the image textures, one 32-bit word each (r | g << 8 | b << 16), row-major

@@ -471,6 +471,14 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         }
         q[0] = bits(kind);
     }
+    // The material kind of every sphere, rect and cylinder sits in its cold record too: the shading then knows after ONE
+    // dependent load (the primitive's cold record) whether the path ends, scatters or needs a rejection sample, instead
+    // of two (cold record -> material record).
+    auto kind_of = [&](int material) { return I[(size_t)(L.off_mat + 3 * material) * 4]; };  // the bits, as a float
+    for (int k = 0; k < ns_slots; ++k)
+        if (slots[k] >= 0) rec4(L.off_sph_cold + k)[3] = kind_of(s.prims[slots[k]].material);
+    for (int k = 0; k < L.nr; ++k) rec4(L.off_rect_cold + k)[2] = kind_of(s.prims[rec[k]].material);
+    for (int k = 0; k < L.nc; ++k) rec4(L.off_cyl_cold + 4 * k)[14] = kind_of(s.prims[cyl[k]].material);
     c.packed_version = s.version;
 }
 
@@ -731,7 +739,10 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // 4000 spheres 20 vs 66 ms), which has no size limit.
     const size_t acc_lds = 4 * 192 * sizeof(unsigned long long);  // one 64-pixel rgb accumulator per wave
     // (only the range-table kernels read the tables at the end of the hot part)
-    auto hot_bytes_of = [&](unsigned v) { return (size_t)(variant_cull_mode(v) == 3 ? P.hot_vec4_tables : P.hot_vec4) * 16; };
+    auto hot_bytes_of = [&](unsigned v) {
+        const int mode = variant_cull_mode(v);
+        return (size_t)((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4) * 16;
+    };
     size_t hot_bytes = hot_bytes_of(variant);
     static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
                                                                              : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;
@@ -751,7 +762,14 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         set_error("kernel variant %u has no build with triangles / image textures (variants 0, 16 and 40 have)", variant);
         return RT_ERR_LIMIT;
     }
-    const size_t lds_bytes = ((variant & 8u) ? 0 : hot_bytes) + acc_lds;
+    // (the work-balanced kernel keeps a work list per wave behind the accumulators: RT_WL_BYTES in render_kernel.hip)
+    const size_t wl_lds = variant_cull_mode(variant) == 4 ? (size_t)4 * (64 * 8 + 64 * 6 * 2 + 16) : 0;
+    if (variant_cull_mode(variant) == 4 && (P.nwin > 1 || s.prims.size() >= 65535 || P.ns >= 65535)) {
+        set_error("kernel variant %u (work-balanced cluster tests) handles one window of 64 clusters and fewer than 65535 objects",
+                  variant);
+        return RT_ERR_LIMIT;
+    }
+    const size_t lds_bytes = ((variant & 8u) ? 0 : hot_bytes) + acc_lds + wl_lds;
     if (lds_bytes > 160 * 1024) {
         set_error("kernel variant %u keeps the scene tables in LDS and this scene needs %zu bytes per workgroup "
                   "(limit 163840); use the default variant",

@@ -56,6 +56,10 @@
 #ifndef RT_ORPHAN_MAX
 #define RT_ORPHAN_MAX 12
 #endif
+// CULL == 4: work-list entries a lane contributes per pass, and the list's capacity per wave
+#define RT_WL_PER_LANE 6
+#define RT_WL_CAP (64 * RT_WL_PER_LANE)
+#define RT_WL_BYTES (4 * (64 * 8 + RT_WL_CAP * 2 + 16))
 // MEASUREMENT ONLY (wrong images; never defined by the Makefile): what a section costs is what the frame gains when it
 // is cut out -- RT_ABLATE=1 rejection loops accept their first candidate, 2 no pixel accumulation, 4 the sample
 // seeding skips Philox, 8 no shading of hits (every hit ends the path)
@@ -190,11 +194,16 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                                                      DevCounters *__restrict__ counters) {
     extern __shared__ float4 lds[];
     // stage the hot tables (hittable_list contents) into LDS
-    const int staged = SCALAR ? 0 : (CULL == 3 ? P.hot_vec4_tables : P.hot_vec4);
+    const int staged = SCALAR ? 0 : ((CULL == 3 || CULL == 4) ? P.hot_vec4_tables : P.hot_vec4);
     for (int i = threadIdx.x; i < staged; i += 256) lds[i] = image[i];
     // per-wave tile accumulator of the current work item: 64 pixels x rgb, 64-bit fixed point
     unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + staged);
     for (int i = threadIdx.x; i < 4 * 64 * 3; i += 256) tile_acc[i] = 0ull;
+    // CULL == 4: per-wave work list of (ray, cluster) items behind the accumulators: 64 result keys, RT_WL_CAP entries
+    // and the entry counter per wave
+    unsigned long long *wl_key = tile_acc + 4 * 192;
+    unsigned short *wl_ent = reinterpret_cast<unsigned short *>(wl_key + 4 * 64);
+    unsigned int *wl_cnt = reinterpret_cast<unsigned int *>(wl_ent + 4 * RT_WL_CAP);
     __syncthreads();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -315,7 +324,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         bool front = false;
         float tex_r = 0, tex_g = 0, tex_b = 0;  // the texel of an image texture at the hit's (u, v)
         if (__any(active)) {
-        if (active) {
+        {   // (declarations for every lane; the work below is guarded by `active` part by part, because the
+            //  work-balanced cluster tests of CULL == 4 need the lanes WITHOUT a live path as well)
             // ---- closest-hit query over the LDS-resident list (hittable_list::hit,
             // object.cuh:23-37).  Wave-uniform trip counts; `best_id` is the grouped id.
             float best_t = INFINITY;
@@ -372,6 +382,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
         if (__builtin_expect(cand, 0)) resolve(IDX, hb, disc);                                 \
     }
+            if (active) {
             // the always-tested prefix (big spheres), four records at a time
             for (int i = 0; i < P.np; i += 4) {
                 const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
@@ -422,6 +433,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     }
                 }
             }
+            }
             tick(1);
             // ---- culling set-up (CULL): aabb::hit (aabb.hpp:15-29) for every live lane, then one wave-wide
             // vote per box; used for the sphere clusters and for each cylinder's bounding box
@@ -467,7 +479,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), blim), fmaxf(lz, uz));
                 return !(tn > tf);
             };
-            if (CULL == 3) {
+            unsigned long long cand4 = 0ull;  // CULL == 4: this lane's candidate clusters (one window)
+            if (active) {
+            if (CULL == 3 || CULL == 4) {
                 // windows of 64 clusters: one mask bit per cluster
                 for (int w0 = 0; w0 < P.nwin; ++w0) {
                     // clip the ray to the window box (the union of its cluster boxes; same margin as every box test)
@@ -518,6 +532,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         const int left = P.ncl - w0 * 64;  // the last window may hold fewer than 64 clusters
                         if (left < 64) cand &= (1ull << left) - 1ull;
                         if (COUNT) c_lane_cands += (uint32_t)__popcll(cand);
+                    }
+                    if (CULL == 4) {  // the candidates are tested below, spread over all lanes of the wave
+                        cand4 = cand;
+                        continue;
                     }
                     // phase 2: keep the candidates whose own box the ray reaches (per-lane box reads)
                     unsigned long long mine = 0ull;
@@ -639,6 +657,116 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 }
                 }
             }
+            }  // if (active): candidate search
+            if (CULL == 4) {
+                // ---- work-balanced cluster tests.  A ray needs 3 candidate clusters on average, the wave's slowest
+                // lane 8.6: walked lane by lane, a wave spends max-over-lanes rounds of 8 sphere tests with 2 of 3 slots
+                // idle.  Here every candidate (ray, cluster) pair of the wave becomes a work item in a per-wave list in
+                // LDS; item i is tested by lane i mod 64, which fetches the ray from its owner's registers
+                // (ds_bpermute), tests the cluster's 8 spheres and merges its closest hit into the owner's result slot
+                // with ONE 64-bit LDS atomic min on the key {t, 0xFFFF - list index, slot}: the smallest key is the
+                // closest hit and, among equal t, the later list entry (hittable_list::hit's tie rule).
+                unsigned long long *wkey = wl_key + wave * 64;
+                unsigned short *went = wl_ent + wave * RT_WL_CAP;
+                unsigned int *wcnt = wl_cnt + wave * 4;
+                wkey[lane] = ~0ull;
+                const float own_t = best_t;  // what the prefix found bounds every candidate root
+                while (__builtin_amdgcn_ballot_w64(cand4 != 0ull) != 0ull) {
+                    // produce: up to RT_WL_PER_LANE entries per lane and pass
+                    if (lane == 0) *wcnt = 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    const int n_mine = min((int)__popcll(cand4), RT_WL_PER_LANE);
+                    unsigned int off = 0u;
+                    if (n_mine) off = atomicAdd(wcnt, (unsigned int)n_mine);
+#pragma unroll
+                    for (int j = 0; j < RT_WL_PER_LANE; ++j) {
+                        if (j < n_mine) {
+                            const int q = (int)__builtin_ctzll(cand4);
+                            cand4 &= cand4 - 1ull;
+                            went[off + j] = (unsigned short)((lane << 6) | q);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int n_ent = __builtin_amdgcn_readfirstlane((int)*(volatile unsigned int *)wcnt);
+                    // consume: 64 items per round
+                    for (int ib = 0; ib < n_ent; ib += 64) {
+                        const bool have = ib + lane < n_ent;
+                        const int e = have ? (int)went[ib + lane] : 0;
+                        const int src = e >> 6, q = e & 63;
+                        // the owner's ray (every lane takes part in the permutes)
+                        const float fox = __shfl(ox, src, 64), foy = __shfl(oy, src, 64), foz = __shfl(oz, src, 64);
+                        const float fdx = __shfl(dx, src, 64), fdy = __shfl(dy, src, 64), fdz = __shfl(dz, src, 64);
+                        const float fra = __shfl(ra, src, 64), frinv = __shfl(rinv_a, src, 64), fbt = __shfl(own_t, src, 64);
+                        if (COUNT) {
+                            c_clusters++;
+                            c_lane_clusters += have ? 1u : 0u;
+                        }
+                        if (have) {
+                            const int base = P.np + (CSIZE + 1) * q;
+                            const float4 *cs = sph + base;
+                            // sphere::hit's discriminant test (object.cuh:47-56) for the cluster's spheres; the roots of
+                            // the few candidates are worked out afterwards, one candidate per lane and round: with 64
+                            // busy lanes some lane has a candidate in every slot, and a sqrt block per slot would run
+                            // for all of them
+                            auto terms = [&](const float4 S, float &hb, float &disc) -> bool {
+                                const float ocx = fox - S.x, ocy = foy - S.y, ocz = foz - S.z;
+                                hb = dot3(ocx, ocy, ocz, fdx, fdy, fdz);
+                                const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -S.w)));
+                                disc = fmaf(hb, hb, -(fra * cc));
+                                return !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);
+                            };
+                            uint32_t cmask = 0u;
+#pragma unroll
+                            for (int h = 0; h < CSIZE; h += 4) {
+                                const float4 r0 = cs[h], r1 = cs[h + 1], r2 = cs[h + 2], r3 = cs[h + 3];
+                                float hb, disc;
+                                if (terms(r0, hb, disc)) cmask |= 1u << h;
+                                if (terms(r1, hb, disc)) cmask |= 2u << h;
+                                if (terms(r2, hb, disc)) cmask |= 4u << h;
+                                if (terms(r3, hb, disc)) cmask |= 8u << h;
+                            }
+                            float lbt = fbt;
+                            int lid = -1;
+                            while (__builtin_amdgcn_ballot_w64(cmask != 0u) != 0ull) {
+                                if (cmask != 0u) {
+                                    const int h = (int)__builtin_ctz(cmask);
+                                    cmask &= cmask - 1u;
+                                    float hb, disc;
+                                    terms(cs[h], hb, disc);
+                                    if (COUNT) c_cand++;
+                                    const float sq = sqrtf(disc);
+                                    float root = (-hb - sq) * frinv;
+                                    if (root < kTMin || lbt < root) root = (-hb + sq) * frinv;
+                                    if (!(root < kTMin || lbt < root)) {
+                                        bool take = true;
+                                        if (root == lbt && lid >= 0)
+                                            take = list_index_of(P, image, base + h) > list_index_of(P, image, lid);
+                                        if (take) lbt = root, lid = base + h;
+                                    }
+                                }
+                            }
+                            if (lid >= 0) {
+                                const unsigned int li = (RT_ABLATE & 16) ? 0u : (unsigned int)list_index_of(P, image, lid);
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(lbt) << 32) |
+                                                               ((unsigned long long)(0xFFFFu - li) << 16) | (unsigned int)lid;
+                                atomicMin(wkey + src, key);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // the owner merges the clusters' closest hit with what its prefix found
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long k = *(volatile unsigned long long *)(wkey + lane);
+                if (active && k != ~0ull) {
+                    const float kt = __uint_as_float((unsigned int)(k >> 32));
+                    const int kid = (int)(k & 0xFFFFu);
+                    bool take = kt < best_t || best_id < 0;
+                    if (!take && kt == best_t) take = (int)(0xFFFFu - ((unsigned int)(k >> 16) & 0xFFFFu)) > list_index_of(P, image, best_id);
+                    if (take) best_t = kt, best_id = kid;
+                }
+            }
+            if (active) {
 #undef RT_SPHERE_TEST
 
             // axis-aligned rects: xy_rect/xz_rect/yz_rect::hit, object.cuh:105-192
@@ -785,6 +913,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     front = dot3(dx, dy, dz, onx, ony, onz) < 0.0f;
                     nx = front ? onx : -onx, ny = front ? ony : -ony, nz = front ? onz : -onz;
                     mat = __float_as_int(cold.y);
+                    kind = __float_as_int(cold.w);
                 } else if (best_id < ns + nr) {
                     const int j = best_id - ns;
                     const int axis = __float_as_int(rect[2 * j + 1].y);
@@ -794,7 +923,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     // front ? (0,0,1) : -(0,0,1), zeros keep their sign as in the reference
                     const float sgn = front ? 1.0f : -1.0f, zer = front ? 0.0f : -0.0f;
                     nx = axis == 2 ? sgn : zer, ny = axis == 1 ? sgn : zer, nz = axis == 0 ? sgn : zer;
-                    mat = __float_as_int(image[P.off_rect_cold + j].x);
+                    const float4 rc = image[P.off_rect_cold + j];
+                    mat = __float_as_int(rc.x);
+                    kind = __float_as_int(rc.z);
                 } else if (best_id < ns + nr + nc) {
                     const int k = best_id - ns - nr;
                     const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2];
@@ -818,6 +949,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     front = dot3(dx, dy, dz, wnx, wny, wnz) < 0.0f;
                     nx = front ? wnx : -wnx, ny = front ? wny : -wny, nz = front ? wnz : -wnz;
                     mat = __float_as_int(cc4[3].x);
+                    kind = __float_as_int(cc4[3].z);
                 } else if (EXT) {  // triangle, taichi-version/hittable.py:254-259: the stored unit normal, turned against the ray
                     const int k = best_id - ns - nr - nc;
                     const float tnx = tri[3 * k].w, tny = tri[3 * k + 1].w, tnz = tri[3 * k + 2].w;
@@ -825,9 +957,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     front = dot3(dx, dy, dz, tnx, tny, tnz) < 0.0f;
                     nx = front ? tnx : -tnx, ny = front ? tny : -tny, nz = front ? tnz : -tnz;
                     mat = __float_as_int(image[P.off_tri_cold + 2 * k].x);
+                    kind = __float_as_int(image[P.off_mat + 3 * mat].x);
                 }
+                // (the material kind rides in the primitive's cold record: one dependent load, not two)
                 const float4 *M = image + P.off_mat + 3 * mat;
-                kind = __float_as_int(M[0].x);
                 // the hit record's (u, v) -- only where the material's texture reads them (an image texture); every
                 // other texture of the reference ignores them, and acos / atan2 per candidate hit (object.cuh:87-93)
                 // would be the most expensive part of sphere::hit
@@ -913,6 +1046,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 path_done = true;
                 if (COUNT) c_misses++;
             }
+            }  // if (active): rects, cylinders, triangles, shading part 1
           }
         }
         tick(3);
@@ -1235,6 +1369,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 #define RT_VARIANT_TABLE(X)        \
     X(0, true, true, false, 3)     \
     X(1, false, true, false, 3)    \
+    X(4, true, true, false, 4)     \
     X(8, true, true, true, 1)      \
     X(16, true, true, false, 0)    \
     X(17, false, true, false, 0)   \

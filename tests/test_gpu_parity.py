@@ -127,7 +127,7 @@ def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
     assert np.abs(acc - whole).max() <= 13 * 2.0 ** -24 * max(1.0, acc.max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 8, 16, 17, 19, 24, 32, 40, 64, 104])
+@pytest.mark.parametrize("variant", [0, 1, 4, 8, 16, 17, 19, 24, 32, 40, 64, 104])
 def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir, variant):
     """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
     bit 1: unbatched sphere loop; bit 3: sphere table read through the scalar cache instead of
@@ -411,3 +411,26 @@ def test_unpinned_edge_cases_on_device(rtmi, rtcheck):
         img = _assert_same(rtmi, rtcheck, sc)
         if want is not None:
             assert np.all(img[4, 4] == np.float32(want) * sc.spp), name
+
+
+def test_big_sheet_uses_range_tables_over_many_windows(rtmi, rtcheck):
+    """3000 small spheres spread over a ground sheet: 375 clusters = 6 windows of 64 clusters, each with its own range
+    tables; 48 KB of sphere records + 36 KB of tables go through global memory (variant 40).  Same bits as the flat
+    scan and the checker; the same scene forced into LDS (one workgroup per CU at that size) too."""
+    sc = rtmi.Scene.new(96, 54, 2, 10)
+    sc.camera((0, 9, 26), (0, 0, 0), (0, 1, 0), 40.0)
+    sc.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
+    rng = np.random.default_rng(17)
+    mats = [sc.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(5)] + [sc.metal((0.8, 0.8, 0.8), 0.05), sc.dielectric(1.5)]
+    sc.sphere((0, -1000, 0), 1000.0, mats[0])
+    for i in range(3000):
+        r = float(rng.uniform(0.05, 0.15))
+        sc.sphere((float(rng.uniform(-20, 20)), r, float(rng.uniform(-20, 20))), r, mats[i % len(mats)])
+    st = sc.count(rtmi.Opts(seed=SEED))
+    assert st.cull_mode == 3 and st.cull_windows == 6 and st.cull_clusters == 375 and st.lane_cands >= st.lane_clusters > 0
+    img = _assert_same(rtmi, rtcheck, sc)
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=1)))   # tables in LDS (90 KB per workgroup)
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=64)))  # the box hierarchy on the same clusters
+    with pytest.raises(rtmi.RtmiError, match="one window"):
+        sc.render(rtmi.Opts(seed=SEED, variant=4))
