@@ -689,8 +689,10 @@ int rto_sample(const rto_scene *s, uint64_t seed, int x, int y, int sample, floa
                rto_counts *counts) {
     rng_t g;
     rng_init(&g, seed, (uint32_t)(y * s->width + x), (uint32_t)sample);
-    float u = ((float)x + random_float(&g)) / (float)(s->width - 1);
-    float v = ((float)y + random_float(&g)) / (float)(s->height - 1);
+    /* u = (i + xi) / (W - 1), cpu/main.cpp:49-50: a multiply by the fp32 reciprocal (equal in real arithmetic; the HIP
+     * kernel saves two IEEE divisions per sample with it) */
+    float u = ((float)x + random_float(&g)) * (1.0f / (float)(s->width - 1));
+    float v = ((float)y + random_float(&g)) * (1.0f / (float)(s->height - 1));
     ray_t r = camera_get_ray(s, u, v, &g);
     int queries = 0;
     vec3 c = ray_color(s, r, s->max_depth, &g, counts, &queries);

@@ -148,8 +148,11 @@ __device__ __forceinline__ int list_index_of(const RenderParams &P, const float4
 // NaN -> 0, magnitude clamped to RT_FIX_CLAMP (2^16).  |sample| <= 2^16 and at most 2^23 samples per pixel
 // (checked by the host) keep every pixel sum below 2^39 < 2^63 / 2^24: the integer sums never wrap.
 __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
+    // |v| < 128 (every sample that is not a look straight into a bright emitter): v * 2^24 is exact (a power of two)
+    // and below 2^31, so round-to-nearest-even and a 32-bit convert give llrint((double)v * 2^24); sign-extended
+    if (fabsf(v) < 128.0f) return (unsigned long long)(long long)(int)rintf(v * 16777216.0f);
     if (!(fabsf(v) <= RT_FIX_CLAMP)) v = (v != v) ? 0.0f : copysignf(RT_FIX_CLAMP, v);
-    // llrint((double)v * 2^24) without fp64: |v| = hi + frac with hi = trunc(|v|) (v_cvt_u32_f32; the
+    // the general case without fp64: |v| = hi + frac with hi = trunc(|v|) (v_cvt_u32_f32; the
     // subtraction of the integer part is exact), frac * 2^24 < 2^24 is exact in fp32 arithmetic before the
     // rounding, and rounding it to nearest even rounds the whole value to nearest even because hi * 2^24 is
     // an even integer.
@@ -215,7 +218,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     const float4 *cyl = hot + P.off_cyl_hot;
     const int ns = P.ns, nr = P.nr, nc = P.nc, nt = P.nt;
     const float4 *tri = hot + P.off_tri_hot;
-    const float wm1 = (float)(P.width - 1), hm1 = (float)(P.height - 1);
+    // u = (x + xi) / (W - 1), main.cu:96-97, evaluated as a multiply by the fp32 reciprocal (as the checker does)
+    const float inv_wm1 = 1.0f / (float)(P.width - 1), inv_hm1 = 1.0f / (float)(P.height - 1);
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
     uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0;
@@ -1158,8 +1162,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 cur_p = sp;
                 slot = -2;
                 rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss, k0, k1);
-                u = ((float)spx + rng_next<COUNT>(rng)) / wm1;
-                v = ((float)spy + rng_next<COUNT>(rng)) / hm1;
+                u = ((float)spx + rng_next<COUNT>(rng)) * inv_wm1;
+                v = ((float)spy + rng_next<COUNT>(rng)) * inv_hm1;
                 if (COUNT) c_samples++;
             }
             started = start;

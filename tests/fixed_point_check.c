@@ -14,6 +14,7 @@ static uint64_t by_definition(float v) {
 
 /* the device expression, operation for operation (v_cvt_u32_f32 truncates, v_rndne_f32 = rintf) */
 static uint64_t as_in_the_kernel(float v) {
+    if (fabsf(v) < 128.0f) return (uint64_t)(int64_t)(int32_t)rintf(v * 16777216.0f); /* the fast path */
     if (!(fabsf(v) <= 65536.0f)) v = (v != v) ? 0.0f : copysignf(65536.0f, v);
     const float a = fabsf(v);
     const uint32_t hi = (uint32_t)a;

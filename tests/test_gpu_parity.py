@@ -295,28 +295,39 @@ def test_full_frame_properties(rtmi, rtcheck):
     assert 0.3 < mean < 0.7 and np.isfinite(full).all() and full.min() >= 0
 
 
+def _axis_parallel_scene(rtmi):
+    """Rays with a direction component of EXACTLY 0, by construction: the camera sits at x = 1000 and looks down -z with
+    a field of view so narrow that `horizontal.x` is far below ulp(1000) -- lower_left.x + u * horizontal.x rounds to the
+    origin's x for every pixel, so d.x = 0 exactly, while the clustered spheres around x = 1000 have boxes with positive
+    faces: the case in which an unclamped 1 / d.x = inf turns the fma-form slab test into inf - inf = NaN."""
+    sc = rtmi.Scene.new(9, 9, 4, 5)
+    sc.set_background((0.25, 0.5, 0.75), sky_gradient=False, defocus_blur=False)
+    sc.camera((1000.0, 0.0, 5.0), (1000.0, 0.0, 0.0), (0, 1, 0), 1e-6, 1.0, 0.0, 5.0)
+    lights = [sc.diffuse_light((1.0 + k, 2.0, 3.0)) for k in range(3)]
+    k = 0
+    for ix in range(-3, 4):          # 7 x 7 small spheres on a lattice in the plane z = 0: 49 spheres -> 7 clusters
+        for iy in range(-3, 4):
+            sc.sphere((1000.0 + 1.5 * ix, 1.5 * iy, 0.0), 0.5, lights[k % 3])
+            k += 1
+    return sc
+
+
 def test_axis_parallel_bounce_is_not_culled(rtmi, rtcheck):
-    """RTIOW 1920x1080, seed 2023, pixel (1745, 128), sample 8: the bounce off a fuzz-free mirror has
-    dy == 0 exactly.  1/dy = inf turned the fma-form slab test (b/d - o/d) into inf - inf = NaN on one
-    face, min/max dropped the NaN together with the whole slab, and the ray skipped the cluster of the
-    sphere it hits (found when every lane started to rely on its own box tests).  The reciprocal is
-    clamped to +-1e18 since."""
-    sc = rtmi.Scene.rtiow(7, 1920, 1080, 1, 50)
-    x, y, smp = 1745, 128, 8
+    """A direction component of exactly 0 (a fuzz-free mirror produces them in the wild: round 1 found RTIOW 1920x1080,
+    pixel (1745, 128), sample 8 with dy == 0): 1/0 = inf turned the fma-form slab test (b/d - o/d) into inf - inf = NaN
+    on one face, min/max dropped the NaN together with the whole slab, and the ray skipped the cluster of the sphere it
+    hits.  The reciprocals are clamped to +-1e18 since.  The case is constructed here instead of searched for."""
+    sc = _axis_parallel_scene(rtmi)
     osc = rtcheck.OracleScene(sc)
-    ref, queries = rtcheck.oracle_trace_sample(osc, SEED, x, y, smp)
-    assert len(queries) == 3 and queries[1][4] == 0.0 and queries[1][7] == 1.0  # dy == 0, and it hits
-    rows = {}
-    for variant in (0, 1, 32, 64, 16):
-        o = rtmi.Opts(seed=SEED, variant=variant, sample_first=smp, sample_count=1, tile_rows=1, tile_first=y,
-                      tile_stride=100000)
-        rows[variant] = sc.render(o)
-        assert rows[variant].shape == (1, 1920, 3)
-        # one sample through the exact pixel sum: its 2^-24 fixed-point value, converted back once
-        want = (np.rint(ref.astype(np.float64) * 2.0 ** 24) * 2.0 ** -24).astype(np.float32)
-        assert np.array_equal(rows[variant][0, x], want), variant
-    for variant in (0, 1, 32, 64):
-        assert np.array_equal(rows[variant], rows[16])
+    ref, queries = rtcheck.oracle_trace_sample(osc, SEED, 4, 4, 0)
+    assert len(queries) == 1 and queries[0][3] == 0.0 and queries[0][7] == 1.0  # d.x == 0 exactly, and the ray hits
+    assert abs(queries[0][6] - 0.9) < 1e-3                                      # the sphere at (1000, 0, 0), t = 4.5 / 5
+    imgs = {}
+    for variant in (0, 1, 4, 32, 64, 16):
+        imgs[variant] = _assert_same(rtmi, rtcheck, sc, variant=variant)
+        assert np.all(imgs[variant][4, 4] == np.float32([4.0, 8.0, 12.0]))  # 4 spp x the lattice centre's light (1, 2, 3)
+    for variant in (0, 1, 4, 32, 64):
+        assert np.array_equal(imgs[variant], imgs[16])
 
 
 def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
