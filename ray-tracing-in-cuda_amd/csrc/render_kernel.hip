@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     unsigned int *wl_cnt = reinterpret_cast<unsigned int *>(wl_ent + 4 * RT_WL_CAP);
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (wave: in a scalar register)
     unsigned long long *my_acc = tile_acc + wave * 192;
     const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
     const float4 *hot = SCALAR ? image : lds;
