@@ -193,8 +193,10 @@ int rt_scene_add_cylinder(rt_scene *s, float radius, float zmin, float zmax, int
  * The hit record's u, v (sphere object.cuh:87-93, rects :113-114, cylinder :283-288, triangle hittable.py:233)
  * are only evaluated for hits on materials with an image texture. */
 int rt_scene_add_image_texture(rt_scene *s, int rows, int cols, const uint8_t *rgb);
-/* the same from a binary or text PPM file (P6 / P3, maxval 255).  The reference's assets are JPEG / PNG files read
- * through OpenCV; convert them once (`python -c "from PIL import Image; Image.open('a.png').convert('RGB').save('a.ppm')"`). */
+/* the same from a file: PNG (8 bits per channel, non-interlaced; grey, grey + alpha, RGB, RGBA or palette; alpha is
+ * dropped) or binary / text PPM (P6 / P3, maxval 255).  The reference reads its assets through OpenCV, and two of its
+ * three "*.png" textures are JPEG files: convert those once
+ * (`python -c "from PIL import Image; Image.open('bricks2.png').convert('RGB').save('bricks2.ppm')"`). */
 int rt_scene_add_image_texture_file(rt_scene *s, const char *path);
 /* rows / cols of image texture `texture` and, if out != NULL, its rows*cols*3 bytes; -rt_status on error */
 int rt_scene_get_image(const rt_scene *s, int texture, int *rows, int *cols, uint8_t *out, size_t cap);

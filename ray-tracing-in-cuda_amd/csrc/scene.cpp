@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "json.hpp"
+#include "png_read.hpp"
 #include "philox.h"
 
 namespace rtmi {
@@ -288,6 +289,28 @@ static int read_ppm(const char *path, int &rows, int &cols, std::vector<uint8_t>
 int add_image_texture_file(Scene &s, const char *path) {
     int rows = 0, cols = 0;
     std::vector<uint8_t> rgb;
+    // PNG by signature (8-bit, non-interlaced), else PPM
+    bool is_png = false;
+    if (FILE *fp = fopen(path, "rb")) {
+        unsigned char sig[8] = {0};
+        is_png = fread(sig, 1, 8, fp) == 8 && sig[0] == 137 && sig[1] == 'P' && sig[2] == 'N' && sig[3] == 'G';
+        std::vector<uint8_t> file;
+        if (is_png) {
+            fseek(fp, 0, SEEK_SET);
+            unsigned char chunk[65536];
+            size_t n;
+            while ((n = fread(chunk, 1, sizeof chunk, fp)) > 0) file.insert(file.end(), chunk, chunk + n);
+        }
+        fclose(fp);
+        if (is_png) {
+            std::string err;
+            if (!png::read(file, rows, cols, rgb, err)) {
+                set_error("%s: %s", path, err.c_str());
+                return -RT_ERR_IO;
+            }
+            return add_image_texture(s, rows, cols, rgb.data(), path);
+        }
+    }
     int rc = read_ppm(path, rows, cols, rgb);
     if (rc) return -rc;
     return add_image_texture(s, rows, cols, rgb.data(), path);

@@ -284,3 +284,69 @@ def test_many_triangles_are_culled_by_their_boxes(rtmi, rtcheck):
     assert np.array_equal(a, sc.render(rtmi.Opts(seed=SEED, variant=16)))
     ref, _ = rtcheck.oracle_render(sc, seed=SEED)
     assert np.array_equal(a, ref)
+
+
+def _png_bytes(px, color_type, filters, level=9, palette=None):
+    """A PNG file made by hand (zlib from the standard library): px = (rows, cols, channels) uint8."""
+    import struct, zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    rows, cols, ch = px.shape
+    raw = bytearray()
+    prev = np.zeros(cols * ch, dtype=np.int32)
+    for y in range(rows):
+        cur = px[y].reshape(-1).astype(np.int32)
+        f = filters[y % len(filters)]
+        a = np.concatenate([np.zeros(ch, dtype=np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, dtype=np.int32), prev[:-ch]])
+        if f == 0: pred = 0 * cur
+        elif f == 1: pred = a
+        elif f == 2: pred = prev
+        elif f == 3: pred = (a + prev) // 2
+        else:
+            p = a + prev - c
+            pa, pb, pc = abs(p - a), abs(p - prev), abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        raw.append(f)
+        raw += bytes(((cur - pred) & 255).astype(np.uint8))
+        prev = cur
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", cols, rows, 8, color_type, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(np.asarray(palette, dtype=np.uint8).reshape(-1)))
+    z = zlib.compress(bytes(raw), level)
+    out += chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:])  # split over two IDAT chunks
+    return out + chunk(b"IEND", b"")
+
+
+def test_png_textures(rtmi, tmp_path):
+    rng = np.random.default_rng(8)
+    smooth = (np.add.outer(np.arange(40) * 5, np.arange(33) * 3)[:, :, None] + np.arange(4)[None, None, :] * 40) % 256
+    noisy = rng.integers(0, 256, size=(17, 23, 4))
+    for name, base in (("smooth", smooth), ("noisy", noisy)):
+        base = base.astype(np.uint8)
+        for ctype, ch in ((2, 3), (6, 4), (0, 1), (4, 2)):
+            px = np.ascontiguousarray(base[:, :, :ch])
+            for level in (0, 1, 9):  # stored blocks, fixed and dynamic Huffman codes
+                f = tmp_path / f"{name}_{ctype}_{level}.png"
+                f.write_bytes(_png_bytes(px, ctype, filters=[0, 1, 2, 3, 4], level=level))
+                sc = rtmi.Scene.new(16, 16, 1)
+                tex = sc.image_texture(str(f))
+                want = px[:, :, :3] if ch >= 3 else np.repeat(px[:, :, :1], 3, axis=2)
+                assert np.array_equal(sc.get_image(tex), want), (name, ctype, level)
+    # palette
+    idx = rng.integers(0, 5, size=(9, 11, 1)).astype(np.uint8)
+    pal = rng.integers(0, 256, size=(5, 3)).astype(np.uint8)
+    f = tmp_path / "pal.png"
+    f.write_bytes(_png_bytes(idx, 3, filters=[0], palette=pal))
+    sc = rtmi.Scene.new(16, 16, 1)
+    assert np.array_equal(sc.get_image(sc.image_texture(str(f))), pal[idx[:, :, 0]])
+    # a JPEG called .png (what the reference's asset/tex/bricks2.png is) and a truncated PNG are errors, not garbage
+    (tmp_path / "fake.png").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    with pytest.raises(rtmi.RtmiError):
+        sc.image_texture(str(tmp_path / "fake.png"))
+    good = _png_bytes(smooth[:, :, :3].astype(np.uint8), 2, filters=[4])
+    (tmp_path / "cut.png").write_bytes(good[: len(good) // 2])
+    with pytest.raises(rtmi.RtmiError):
+        sc.image_texture(str(tmp_path / "cut.png"))
