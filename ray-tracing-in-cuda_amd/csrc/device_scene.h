@@ -91,6 +91,11 @@ struct RenderParams {
     int32_t off_cbox;        // 2 float4 per cylinder: world-space bounding box of the open tube
     // range tables: per window {box min.xyz}, {1 / slab width .xyz}, then per enabled axis RT_SLABS^2 64-bit masks
     int32_t off_rtab, rt_stride, rt_axes;  // float4 offset, float4 records per window, enabled axes (bit a)
+    // uniform grid over the clustered spheres (CULL == 5): 4 header records, cells (one 32-bit word each: first item << 8 |
+    // count), items (16-bit sphere slots); grid_cells == 0: the scene has no grid (no clustered spheres, or a cell with
+    // more than 255 spheres)
+    int32_t off_grid, off_grid_cells, off_grid_items, grid_cells;
+    int32_t hot_vec4_grid;   // float4 count of the hot part through the grid tables (what the grid-walk kernel stages)
     int32_t hot_vec4_tables; // float4 count of the hot part including the range tables (what the range-table kernel stages)
     float cull_extent1;      // 1 + max |coordinate| of the clustered spheres (per-lane box margin, see packer)
     int32_t hot_vec4;        // float4 count of the hot part without the range tables (LDS bytes / 16 of the other variants)

@@ -219,7 +219,124 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     int n_axes = (axes & 1) + ((axes >> 1) & 1) + ((axes >> 2) & 1);
     L.off_gbox = off;  // outer boxes: the box-hierarchy variants read them
     off += 2 * n_groups;
-    L.hot_vec4 = off;  // what every variant but the range-table kernel stages into LDS
+    L.hot_vec4 = off;  // what the box-hierarchy and flat-scan variants stage into LDS
+    // ---- uniform grid over the clustered spheres (the default candidate search, CULL == 5: every lane walks the
+    // cells its ray crosses front to back -- 3-D DDA -- and tests the spheres listed in them).
+    // A sphere is listed in every cell its GROWN box touches.  The growth covers the fp32 error of the sphere test:
+    // |disc_fp32 - disc| <= K eps a |oc|^2 (K = 32 bounds the operation-by-operation sum, about 15 eps |oc|^2), so a
+    // ray the fp32 test can accept passes within r' = sqrt(r^2 + K eps |oc|^2) of the centre, and its fp32 hit point lies
+    // inside that ball too.  |oc| <= |o| + |c|, so the growth depends on how far from the coordinate origin a ray starts;
+    // the lists come in two tiers:
+    //   near  |o| <= ob_near (the cloud, the camera; RTIOW 23.4): the first n_near entries of a cell's list
+    //   far   |o| <= ob_far  (hits on distant ground; 8x the cloud, at least 64): all n_all entries
+    // and lanes further out still test the grid's bounds with the per-lane margin of the box tests and, if they can reach
+    // it at all, scan every clustered sphere: rare, and the flat scan is the definition of the result.
+    // (0.004 cell + 1e-5 (max|c| + 1)) more covers the walk's own rounding: the entry point, the cell boundaries, up to
+    // 255 accumulated leave distances.)
+    std::vector<uint32_t> grid_cells;   // (first item << 12) | (n_near << 6) | n_all
+    std::vector<uint16_t> grid_items;   // sphere slots; a cell's near-tier entries first
+    float grid_min[3] = {0, 0, 0}, grid_size[3] = {1, 1, 1};
+    int grid_n[3] = {0, 0, 0};
+    float grid_ob2[2] = {0.0f, 0.0f}, grid_shrink = 0.0f;
+    {
+        static const double cell_factor = getenv("RTMI_GRID_CELL") ? atof(getenv("RTMI_GRID_CELL")) : 1.0;
+        static const double ob_env = getenv("RTMI_GRID_OB") ? atof(getenv("RTMI_GRID_OB")) : 0.0;  // experiments
+        bool ok = !rest.empty() && ns_slots < 65536;
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, cmax = 0.0, cmax2 = 0.0;
+        for (int i : rest) {
+            double c2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double c = (double)s.prims[i].f[a];
+                lo[a] = std::min(lo[a], c), hi[a] = std::max(hi[a], c);
+                cmax = std::max(cmax, std::fabs(c)), c2 += c * c;
+            }
+            cmax2 = std::max(cmax2, std::sqrt(c2));
+        }
+        if (ok) {
+            const double cam = std::sqrt(s.cam.lookfrom[0] * s.cam.lookfrom[0] + s.cam.lookfrom[1] * s.cam.lookfrom[1] +
+                                         s.cam.lookfrom[2] * s.cam.lookfrom[2]) + std::fabs(s.cam.aperture);
+            const double ob_near = ob_env > 0.0 ? ob_env : std::max(1.5 * cmax2, 1.1 * cam + 1.0);
+            const double ob_far = std::max(std::max(64.0, 8.0 * cmax2), 4.0 * ob_near);
+            grid_ob2[0] = (float)(ob_near * ob_near * (1.0 - 1e-5)), grid_ob2[1] = (float)(ob_far * ob_far * (1.0 - 1e-5));
+            double ext[3], big = 0.0;
+            for (int a = 0; a < 3; ++a) ext[a] = hi[a] - lo[a], big = std::max(big, ext[a]);
+            int dims = 0;
+            double measure = 1.0;
+            bool spread[3];
+            for (int a = 0; a < 3; ++a) {
+                spread[a] = ext[a] > 0.05 * big;
+                if (spread[a]) ++dims, measure *= ext[a];
+            }
+            // cell edge: a multiple of the spacing of the centres (measured on RTIOW, one sphere per unit square)
+            double cell = dims ? std::pow(measure / (double)rest.size(), 1.0 / dims) * cell_factor : 1.0;
+            if (!(cell > 0.0)) cell = 1.0;
+            std::vector<double> grow_near(rest.size()), grow_far(rest.size());
+            double rmax_near = 0.0, rmax_far = 0.0;
+            for (;;) {
+                rmax_near = rmax_far = 0.0;
+                for (size_t k = 0; k < rest.size(); ++k) {
+                    const float *sp = s.prims[rest[k]].f;
+                    const double r = std::fabs((double)sp[3]);
+                    const double cn = std::sqrt((double)sp[0] * sp[0] + (double)sp[1] * sp[1] + (double)sp[2] * sp[2]);
+                    const double K = 32.0 * std::ldexp(1.0, -24), walk = 4e-3 * cell + 1e-5 * (cmax + 1.0);
+                    grow_near[k] = std::sqrt(r * r + K * (ob_near + cn) * (ob_near + cn)) + walk;
+                    grow_far[k] = std::sqrt(r * r + K * (ob_far + cn) * (ob_far + cn)) + walk;
+                    rmax_near = std::max(rmax_near, grow_near[k]), rmax_far = std::max(rmax_far, grow_far[k]);
+                }
+                long long total = 1;
+                for (int a = 0; a < 3; ++a) {
+                    const double span = ext[a] + 2.0 * rmax_far;
+                    grid_n[a] = spread[a] ? (int)std::min(255.0, std::max(1.0, std::ceil(span / cell))) : 1;
+                    grid_min[a] = (float)(lo[a] - rmax_far);
+                    grid_size[a] = (float)(span / grid_n[a]);
+                    total *= grid_n[a];
+                }
+                if (total <= (1 << 18)) break;
+                cell *= 1.3;
+            }
+            // near-tier lanes clip their rays to the bounds of the near-tier boxes: the far tier's, this much further in
+            grid_shrink = (float)((rmax_far - rmax_near) * (1.0 - 1e-6));
+            const int nx = grid_n[0], ny = grid_n[1], nz = grid_n[2];
+            std::vector<std::vector<uint16_t>> lists((size_t)nx * ny * nz), extra((size_t)nx * ny * nz);
+            for (size_t k = 0; k < rest.size(); ++k) {
+                // the slot of this sphere: clusters of csize behind the prefix, one padding slot per cluster
+                const int slot = np_slots + (int)(k / csize) * cstride + (int)(k % csize);
+                int c0[3], c1[3], n0[3], n1[3];
+                for (int a = 0; a < 3; ++a) {
+                    const double c = (double)s.prims[rest[k]].f[a];
+                    auto cell_of = [&](double x) {
+                        const int i = (int)std::floor((x - (double)grid_min[a]) / (double)grid_size[a]);
+                        return std::min(std::max(i, 0), grid_n[a] - 1);
+                    };
+                    c0[a] = cell_of(c - grow_far[k]), c1[a] = cell_of(c + grow_far[k]);
+                    n0[a] = cell_of(c - grow_near[k]), n1[a] = cell_of(c + grow_near[k]);
+                }
+                for (int iz = c0[2]; iz <= c1[2]; ++iz)
+                    for (int iy = c0[1]; iy <= c1[1]; ++iy)
+                        for (int ix = c0[0]; ix <= c1[0]; ++ix) {
+                            const bool near = ix >= n0[0] && ix <= n1[0] && iy >= n0[1] && iy <= n1[1] && iz >= n0[2] && iz <= n1[2];
+                            (near ? lists : extra)[((size_t)iz * ny + iy) * nx + ix].push_back((uint16_t)slot);
+                        }
+            }
+            grid_cells.resize(lists.size());
+            for (size_t c = 0; c < lists.size() && ok; ++c) {
+                const size_t n_near = lists[c].size(), n_all = n_near + extra[c].size();
+                if (n_all > 63 || grid_items.size() + n_all >= (1u << 20)) ok = false;  // a clump: keep the cluster search
+                grid_cells[c] = ((uint32_t)grid_items.size() << 12) | ((uint32_t)n_near << 6) | (uint32_t)n_all;
+                grid_items.insert(grid_items.end(), lists[c].begin(), lists[c].end());
+                grid_items.insert(grid_items.end(), extra[c].begin(), extra[c].end());
+            }
+        }
+        if (!ok) grid_cells.clear(), grid_items.clear(), grid_n[0] = grid_n[1] = grid_n[2] = 0;
+    }
+    L.grid_cells = (int)grid_cells.size();
+    L.off_grid = off;  // 4 records {min.xyz, ob_near^2} {1/size.xyz, ob_far^2} {size.xyz, shrink} {nx, ny, nz, -}, then cells, then items
+    off += 4;
+    L.off_grid_cells = off;
+    off += ((int)grid_cells.size() + 3) / 4;
+    L.off_grid_items = off;
+    off += ((int)grid_items.size() + 7) / 8;
+    L.hot_vec4_grid = off;  // what the grid-walk kernel stages into LDS
     L.rt_axes = axes;
     L.rt_stride = 2 + n_axes * (RT_SLABS * RT_SLABS / 2);  // float4 records per window: {min, 1/width} + masks (2 per record)
     L.off_rtab = off;
@@ -391,6 +508,18 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
             }
             ++ai;
         }
+    }
+    {  // grid tables
+        float *g = rec4(L.off_grid);
+        for (int a = 0; a < 3; ++a) {
+            g[a] = grid_min[a];
+            g[4 + a] = grid_size[a] > 0.0f ? 1.0f / grid_size[a] : 0.0f;
+            g[8 + a] = grid_size[a];
+            g[12 + a] = bits(grid_n[a]);
+        }
+        g[3] = grid_ob2[0], g[7] = grid_ob2[1], g[11] = grid_shrink;
+        if (!grid_cells.empty()) memcpy(rec4(L.off_grid_cells), grid_cells.data(), grid_cells.size() * sizeof(uint32_t));
+        if (!grid_items.empty()) memcpy(rec4(L.off_grid_items), grid_items.data(), grid_items.size() * sizeof(uint16_t));
     }
     for (int k = 0; k < L.nr; ++k) {
         const rt_prim &p = s.prims[rec[k]];
@@ -741,7 +870,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // (only the range-table kernels read the tables at the end of the hot part)
     auto hot_bytes_of = [&](unsigned v) {
         const int mode = variant_cull_mode(v);
-        return (size_t)((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4) * 16;
+        return (size_t)(mode == 5 ? P.hot_vec4_grid : ((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4)) * 16;
     };
     size_t hot_bytes = hot_bytes_of(variant);
     static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
@@ -758,6 +887,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     if (variant == 0 && hot_bytes > global_threshold) variant = 40;
     if (variant == 64 && hot_bytes > global_threshold) variant = 104;
     hot_bytes = hot_bytes_of(variant);
+    if (variant_cull_mode(variant) == 5 && P.grid_cells == 0 && P.ncl > 0) {
+        set_error("kernel variant %u walks the uniform grid, which this scene does not have (more than 65535 sphere slots, "
+                  "or more than 63 spheres in one cell)", variant);
+        return RT_ERR_LIMIT;
+    }
     if (ext && !variant_has_ext(variant)) {
         set_error("kernel variant %u has no build with triangles / image textures (variants 0, 16 and 40 have)", variant);
         return RT_ERR_LIMIT;

@@ -82,7 +82,7 @@ def test_random_geometry_every_candidate_search_equals_the_flat_scan(rtmi, rtche
         st = sc.count(rtmi.Opts(seed=case))
         flat = sc.render(rtmi.Opts(seed=case, variant=16))
         what = f"case {case}: n {n} sheet {sheet} half {half:.1f} inside {inside} {w}x{h}x{spp} mode {st.cull_mode} windows {st.cull_windows}"
-        variants = [0, 1, 40, 64, 104, 32]
+        variants = [0, 1, 40, 64, 104, 32, 128, 136]
         if st.cull_windows <= 1:
             variants.append(4)
         for v in variants:

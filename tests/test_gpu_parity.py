@@ -127,7 +127,7 @@ def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
     assert np.abs(acc - whole).max() <= 13 * 2.0 ** -24 * max(1.0, acc.max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 8, 16, 17, 19, 24, 32, 40, 64, 104])
+@pytest.mark.parametrize("variant", [0, 1, 4, 8, 16, 17, 19, 24, 32, 40, 64, 104, 128, 136])
 def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir, variant):
     """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
     bit 1: unbatched sphere loop; bit 3: sphere table read through the scalar cache instead of
