@@ -61,6 +61,9 @@ F_SCATTER = [40, 55, 65, 0]  # lambertian, metal, dielectric, diffuse_light
 F_MISS = 25            # sky / background evaluation
 F_BOX = 12             # slab test of one box: 6 fma (the min/max/compare that follow count 0)
 F_CULL_SETUP = 17      # per query: 3 reciprocals, margin (mul + add), 6 shifted origins (add + mul each)
+F_GRID_SETUP = 8       # per query: 3 reciprocals, |o|^2 (mul + 2 fma)
+F_GRID_ENTER = 27      # per lane that reaches the grid: entry point 3 fma, cell index 3 x (sub + mul), leave distances 3 x (fma + sub + mul), step lengths 3 mul
+F_GRID_STEP = 2        # per cell step: one leave distance += step length, best_t x (1 + 1e-4); min / compare / select = 0
 F_RANGE_LOOKUP = 24    # per window box a ray reaches: 6 fma for the clipped segment's end points, 2 axes x (2 margin + 2 offset + 2 scale)
 
 
@@ -291,8 +294,10 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
         shading = linear_flops - per_query_linear * c["queries"]  # 46 S + 30 H + scatter + 25 M
         flops_strict = 17 * sphere_tests + n_other * c["queries"] + shading            # box tests = accelerator overhead
         flops = flops_strict + F_BOX * box_tests + setup
-        roof["mode"] = ("culled hittable_list: candidate clusters from range tables, per-lane cluster lists (default kernel)"
-                        if culled else "linear hittable_list scan (variant 16)")
+        search = {5: "uniform grid, per-lane 3-D DDA over two-tier cell lists (default kernel)",
+                  3: "candidate clusters from range tables, per-lane cluster lists", 4: "range tables, work-balanced cluster tests",
+                  2: "per-lane cluster lists through the two-level box hierarchy"}.get(c.get("cull_mode"), "clusters")
+        roof["mode"] = f"culled hittable_list: {search}" if culled else "linear hittable_list scan (variant 16)"
         if args.variant in (8, 32):  # the diagnostic kernel is the default one: its counts do not describe these
             roof["mode"] = "ablation variant with wave-level cluster votes: no flop count"
             flops = flops_strict = 0
@@ -302,13 +307,14 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
             roof["frac_excluding_box_tests"] = round(flops_strict / (k_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)
         roof["flops_per_launch"] = int(flops)
         roof["accounting"] = ("SURVEY 8(d): flops = 46 S + 17 T_sphere + 12 T_box (6 fma; min/max/compare = 0) + per-query "
-                              "culling set-up + 30 H + 40/55/65 B + 25 M, with the sphere and box tests the kernel's lanes "
+                              "culling set-up (grid: 8 per query + 27 per lane that enters + 2 per cell step) "
+                              "+ 30 H + 40/55/65 B + 25 M, with the sphere and box tests the kernel's lanes "
                               "EXECUTE (masked-off lanes not counted), all counted exactly by the diagnostic kernel; "
                               "frac_excluding_box_tests counts the accelerator's own work as 0")
-        roof["frac_note"] = ("the fraction counts the flops of the tests the kernel EXECUTES: round 2's candidate search executes "
-                             "45 % fewer of them per frame than round 1's (2.9e12 against 5.2e12 flops, same accounting) in 13 % less "
-                             "time, so the fraction fell (0.146 -> 0.09) while Msamples/s rose; roofline_linear_scan is the same "
-                             "kernel made to execute the reference's O(N) scan")
+        roof["frac_note"] = ("the fraction counts the flops of the tests the kernel EXECUTES; each round's candidate search executes "
+                             "fewer of them per frame (round 1 box hierarchy 5.2e12, round 2 range tables 2.9e12, the grid walk "
+                             "fewer again) in less time, so the fraction falls while Msamples/s rises; roofline_linear_scan is the "
+                             "same kernel made to execute the reference's O(N) scan")
         roof["counts"] = {k: c[k] for k in ("samples", "queries", "prim_tests", "hits", "misses", "scatter",
                                             "rng_draws", "wave_queries", "clusters_visited", "groups_visited",
                                             "lane_clusters", "lane_groups", "lane_cands") if k in c}
@@ -349,6 +355,12 @@ def executed_tests(c: dict, lanes: float):
     """Ray-primitive and box tests the default kernel's lanes execute, from the diagnostic counters.
     Returns (sphere tests, box tests, per-query set-up flops)."""
     q = c["queries"]
+    if c.get("cull_mode", 2) == 5:
+        # uniform grid: every live lane tests the always-tested prefix and clips its ray against the grid's bounds (one box
+        # test); lanes that reach it compute their entry cell and walk: one sphere test per list entry of every cell
+        # visited (lane_clusters counts single spheres here), one step per further cell
+        return (q * c["cull_prefix"] + c["lane_clusters"], q,
+                F_GRID_SETUP * q + F_GRID_ENTER * c["lane_groups"] + F_GRID_STEP * c["lane_cands"])
     if c.get("cull_mode", 2) == 4:
         # work-balanced ablation: no per-cluster box tests; every candidate cluster's spheres are tested (by some lane)
         return (q * c["cull_prefix"] + c["lane_clusters"] * c["cull_cluster_size"], q * c["cull_windows"],

@@ -250,12 +250,13 @@ typedef struct rt_opts {
     int32_t spp_chunk;
     int32_t sample_first; /* render samples [sample_first, sample_first+count) */
     int32_t sample_count; /* 0 -> scene spp                                    */
-    uint32_t variant;     /* 0 = default kernel; ablation builds (same results): bit 0 strict
-                             one-lane-per-pixel, bit 1 no LDS prefetch (linear scans), bit 3 scalar-cache table,
-                             bit 4 no cluster culling (linear scan of every sphere), bit 5 wave-level
-                             cluster votes, bit 6 per-lane cluster lists through the two-level box hierarchy
-                             instead of the range tables (round 1's default); 40 / 104 = variant 0 / 64 with all
-                             tables in global memory (what they switch to for scenes too large for LDS) */
+    uint32_t variant;     /* 0 = default kernel (uniform-grid walk); ablation and fallback builds (same results):
+                             bit 0 strict one-lane-per-pixel, bit 1 no LDS prefetch (linear scans), bit 3 tables in
+                             global memory, bit 4 no culling (linear scan of every sphere), bit 5 wave-level cluster
+                             votes, bit 6 per-lane cluster lists through the two-level box hierarchy (round 1's
+                             default), bit 7 per-lane cluster lists through the range tables (what scenes without a
+                             grid fall back to); 40 / 104 / 136 = variant 0 / 64 / 128 with all tables in global
+                             memory (what they switch to for scenes too large for LDS) */
 } rt_opts;
 
 typedef struct rt_stats {
@@ -269,10 +270,10 @@ typedef struct rt_stats {
     uint64_t rng_draws;
     uint64_t cand_lanes, cand_waves; /* sphere candidates that reached the sqrt block: lanes / wave entries */
     uint64_t clusters_visited;       /* culling: rounds of the per-lane cluster walk, per wave (= clusters a wave tested
-                                        when it votes as a whole) */
+                                        when it votes as a whole); grid: sphere-test passes per wave */
     uint64_t wave_queries;           /* closest-hit queries executed, counted per WAVE */
     uint64_t groups_visited;         /* culling: outer boxes that passed, per wave; range tables: rounds of the per-lane
-                                        candidate box tests, per wave */
+                                        candidate box tests, per wave; grid: cell-step passes per wave */
     uint64_t lane_clusters;          /* culling: cluster boxes that passed, per LANE (what each ray needs) */
     uint64_t lane_groups;            /* culling: outer boxes that passed, per LANE; range tables: window boxes reached */
     uint64_t group_maxpop;           /* culling: max over lanes of needed clusters, summed over visited groups */
@@ -283,9 +284,11 @@ typedef struct rt_stats {
     double wave_start_spread_us, wave_end_spread_us, wave_span_us; /* first-to-last wave start / exit, first start
                                         to last exit (s_memrealtime) */
     /* rt_render_hip_tiles only: kernel_ms above is the SLOWEST device's render launches */
-    uint64_t lane_cands;  /* culling by range tables: candidate clusters per LANE before the per-cluster box test */
-    int32_t cull_mode;    /* candidate search of the kernel that ran: 3 range tables, 2 box hierarchy per lane, 1 wave
-                             votes, 0 none (flat scan) */
+    uint64_t lane_cands;  /* culling by range tables: candidate clusters per LANE before the per-cluster box test;
+                             grid: cell steps per LANE (lane_groups = lanes that entered the grid, lane_clusters =
+                             sphere tests per LANE) */
+    int32_t cull_mode;    /* candidate search of the kernel that ran: 5 uniform grid, 3 range tables, 2 box hierarchy
+                             per lane, 1 wave votes, 0 none (flat scan) */
     int32_t cull_windows; /* windows of 64 clusters */
     double gather_ms;     /* root device: end of its own render -> assembled frame (ncclGather + row placement,
                              includes waiting for slower peers) */

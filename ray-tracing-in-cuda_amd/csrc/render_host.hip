@@ -267,8 +267,10 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
                 spread[a] = ext[a] > 0.05 * big;
                 if (spread[a]) ++dims, measure *= ext[a];
             }
-            // cell edge: a multiple of the spacing of the centres (measured on RTIOW, one sphere per unit square)
-            double cell = dims ? std::pow(measure / (double)rest.size(), 1.0 / dims) * cell_factor : 1.0;
+            // cell edge: a multiple of the spacing of the centres.  Measured: RTIOW (a sheet, one sphere per unit square)
+            // 1.0 / 1.25 / 1.5 / 2.0 x -> 41.5 / 39.9 / 42.0 / 42.0 ms per 256 spp; 4000 spheres in a volume 0.7 / 1.0 /
+            // 1.4 x -> 6.4 / 6.7 / 7.3 ms, 20000: 12.3 / 12.7 / 15.1 ms (RTMI_GRID_CELL scales the choice).
+            double cell = dims ? std::pow(measure / (double)rest.size(), 1.0 / dims) * (dims == 3 ? 0.85 : 1.25) * cell_factor : 1.0;
             if (!(cell > 0.0)) cell = 1.0;
             std::vector<double> grow_near(rest.size()), grow_far(rest.size());
             double rmax_near = 0.0, rmax_far = 0.0;
@@ -863,37 +865,39 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
 
     // LDS per workgroup: the hot tables (unless the variant reads them from global memory: bit 3) + one
     // tile accumulator per wave.  The default kernel keeps the tables in LDS while that still leaves room
-    // for the kernel's full occupancy (RT_WAVES_PER_SIMD workgroups per CU: RTIOW's 484 spheres 249 vs 253
-    // ms); larger scenes run the same algorithm over global memory (variant 40: 1000 spheres 6.4 vs 6.9 ms,
-    // 4000 spheres 20 vs 66 ms), which has no size limit.
+    // for the kernel's full occupancy (RT_WAVES_PER_SIMD workgroups per CU); larger scenes run the same
+    // algorithm over global memory (variant 40: 4000 spheres 6.7 vs 19 ms), which has no size limit.
     const size_t acc_lds = 4 * 192 * sizeof(unsigned long long);  // one 64-pixel rgb accumulator per wave
-    // (only the range-table kernels read the tables at the end of the hot part)
+    // (each candidate search stages the part of the hot tables it reads)
     auto hot_bytes_of = [&](unsigned v) {
         const int mode = variant_cull_mode(v);
         return (size_t)(mode == 5 ? P.hot_vec4_grid : ((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4)) * 16;
     };
-    size_t hot_bytes = hot_bytes_of(variant);
     static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
                                                                              : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;
-    // The default candidate search is chosen per scene.  The range tables give the clusters a ray segment's BOUNDING BOX
-    // touches: sharp where the clustered spheres lie on a sheet (RTIOW: segments inside the sphere layer are short;
-    // 53.5 against 62.0 ms per 256 spp) or are few, blunt where they fill a volume -- a ray crosses the whole cloud and
-    // its box covers most of it (4000 random spheres: 27.8 against 20 ms).  Volumes keep the box hierarchy (bit 6).
-    {
-        const int n_axes = (P.rt_axes & 1) + ((P.rt_axes >> 1) & 1) + ((P.rt_axes >> 2) & 1);
-        if (variant == 0 && n_axes == 3 && P.ncl > 16 && !ext) variant = 64;  // (the EXT builds are range-table kernels)
+    // The default candidate search is the uniform grid (RTIOW 40 against 57 ms per 256 spp for the range tables; 4000
+    // random spheres in a volume 6.7 against 21 ms for the box hierarchy).  Scenes whose clustered spheres have no grid
+    // (65536 sphere slots or more, or a clump of more than 63 in one cell) keep round 2's choice: the range tables -- the
+    // clusters a ray segment's BOUNDING BOX touches, sharp where the spheres lie on a sheet or are few -- and the box
+    // hierarchy (bit 6) where they fill a volume.
+    if (variant == 0) {
+        if (P.grid_cells > 0 || P.ncl == 0) {
+            if (hot_bytes_of(0) > global_threshold) variant = 40;
+        } else {
+            const int n_axes = (P.rt_axes & 1) + ((P.rt_axes >> 1) & 1) + ((P.rt_axes >> 2) & 1);
+            variant = (n_axes == 3 && P.ncl > 16 && !ext) ? 64 : 128;  // (no EXT build of the box hierarchy)
+            if (variant == 128 && hot_bytes_of(128) > global_threshold) variant = 136;
+        }
     }
-    hot_bytes = hot_bytes_of(variant);
-    if (variant == 0 && hot_bytes > global_threshold) variant = 40;
-    if (variant == 64 && hot_bytes > global_threshold) variant = 104;
-    hot_bytes = hot_bytes_of(variant);
+    if (variant == 64 && hot_bytes_of(64) > global_threshold) variant = 104;
+    size_t hot_bytes = hot_bytes_of(variant);
     if (variant_cull_mode(variant) == 5 && P.grid_cells == 0 && P.ncl > 0) {
         set_error("kernel variant %u walks the uniform grid, which this scene does not have (more than 65535 sphere slots, "
                   "or more than 63 spheres in one cell)", variant);
         return RT_ERR_LIMIT;
     }
     if (ext && !variant_has_ext(variant)) {
-        set_error("kernel variant %u has no build with triangles / image textures (variants 0, 16 and 40 have)", variant);
+        set_error("kernel variant %u has no build with triangles / image textures (variants 0, 16, 40, 128 and 136 have)", variant);
         return RT_ERR_LIMIT;
     }
     // (the work-balanced kernel keeps a work list per wave behind the accumulators: RT_WL_BYTES in render_kernel.hip)

@@ -1469,16 +1469,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 }
 
 // launchers used by render_host.hip
-// X(variant id, POOL, PREFETCH, SCALAR, CULL).  0 is the product default; the others are ablations
-// with identical results: bit 0 = no tile pool (strict one-lane-per-pixel), bit 1 = no LDS prefetch,
-// bit 3 = sphere table through the scalar cache instead of LDS (wave-level cluster votes), bit 4 = no
-// cluster culling (every sphere tested for every query: the reference's linear hittable_list scan),
-// bit 5 = wave-level cluster votes instead of per-lane cluster lists; bit 6 = per-lane lists found through the
-// two-level box hierarchy instead of the range tables (round 1's default); 40 = the default algorithm with all
-// tables in global memory (chosen automatically for scenes too large for LDS), 104 = the same for bit 6
+// X(variant id, POOL, PREFETCH, SCALAR, CULL).  0 is the product default (the uniform-grid walk, CULL 5); the others are
+// ablations and fallbacks with identical results: bit 0 = no tile pool (strict one-lane-per-pixel), bit 1 = no LDS
+// prefetch, bit 3 = tables through global memory instead of LDS, bit 4 = no culling at all (every sphere tested for
+// every query: the reference's linear hittable_list scan), bit 5 = wave-level cluster votes, bit 6 = per-lane cluster
+// lists through the two-level box hierarchy (round 1's default), bit 7 = per-lane cluster lists through the range
+// tables (the fallback for scenes without a grid), 4 = range tables with work-balanced cluster tests;
+// 40 / 104 / 136 = the grid / the box hierarchy / the range tables with all tables in global memory (chosen
+// automatically for scenes too large for LDS)
 #define RT_VARIANT_TABLE(X)        \
-    X(0, true, true, false, 3)     \
-    X(1, false, true, false, 3)    \
+    X(0, true, true, false, 5)     \
+    X(1, false, true, false, 5)    \
     X(4, true, true, false, 4)     \
     X(8, true, true, true, 1)      \
     X(16, true, true, false, 0)    \
@@ -1486,16 +1487,19 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
     X(19, false, false, false, 0)  \
     X(24, true, true, true, 0)     \
     X(32, true, true, false, 1)    \
-    X(40, true, true, true, 3)     \
+    X(40, true, true, true, 5)     \
     X(64, true, true, false, 2)    \
     X(104, true, true, true, 2)    \
-    X(128, true, true, false, 5)   \
-    X(136, true, true, true, 5)
-// variants that also exist with EXT (triangles, image textures): the default, its global-table form, the flat scan
+    X(128, true, true, false, 3)   \
+    X(136, true, true, true, 3)
+// variants that also exist with EXT (triangles, image textures): the default, its global-table form, the flat scan, and the
+// range tables (scenes whose clustered spheres have no grid)
 #define RT_EXT_TABLE(X)            \
-    X(0, true, true, false, 3)     \
+    X(0, true, true, false, 5)     \
     X(16, true, true, false, 0)    \
-    X(40, true, true, true, 3)
+    X(40, true, true, true, 5)     \
+    X(128, true, true, false, 3)   \
+    X(136, true, true, true, 3)
 // every variant exists for both cluster sizes (the linear scans ignore it)
 #define RT_WITH_CSIZE(CALL8, CALL16) \
     if (cluster == 16) { CALL16; } else { CALL8; }
@@ -1509,12 +1513,12 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
 #define RT_COUNT_LAUNCH(SCALAR, CULL)                                                                                                       \
     RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<true, true, true, SCALAR, CULL, 8>), g, t, lds_bytes, stream, P, img, acc, queue, counters),  \
                   hipLaunchKernelGGL((render_kernel<true, true, true, SCALAR, CULL, 16>), g, t, lds_bytes, stream, P, img, acc, queue, counters))
-        if (variant == 128) { RT_COUNT_LAUNCH(false, 5) }
-        else if (variant == 136) { RT_COUNT_LAUNCH(true, 5) }
-        else if (variant == 40) { RT_COUNT_LAUNCH(true, 3) }
+        if (variant == 128) { RT_COUNT_LAUNCH(false, 3) }
+        else if (variant == 136) { RT_COUNT_LAUNCH(true, 3) }
+        else if (variant == 40) { RT_COUNT_LAUNCH(true, 5) }
         else if (variant == 104) { RT_COUNT_LAUNCH(true, 2) }
         else if (variant == 64) { RT_COUNT_LAUNCH(false, 2) }
-        else { RT_COUNT_LAUNCH(false, 3) }
+        else { RT_COUNT_LAUNCH(false, 5) }
 #undef RT_COUNT_LAUNCH
         return;
     }
@@ -1561,12 +1565,12 @@ int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster, b
 #define RT_COUNT_OCC(SCALAR, CULL)                                                                                                          \
     RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 8>, 256, lds_bytes),   \
                   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 16>, 256, lds_bytes))
-        if (variant == 128) { RT_COUNT_OCC(false, 5) }
-        else if (variant == 136) { RT_COUNT_OCC(true, 5) }
-        else if (variant == 40) { RT_COUNT_OCC(true, 3) }
+        if (variant == 128) { RT_COUNT_OCC(false, 3) }
+        else if (variant == 136) { RT_COUNT_OCC(true, 3) }
+        else if (variant == 40) { RT_COUNT_OCC(true, 5) }
         else if (variant == 104) { RT_COUNT_OCC(true, 2) }
         else if (variant == 64) { RT_COUNT_OCC(false, 2) }
-        else { RT_COUNT_OCC(false, 3) }
+        else { RT_COUNT_OCC(false, 5) }
 #undef RT_COUNT_OCC
     } else {
 #define RT_OCC(V, POOL, PRE, SCALAR, CULL)                                                                                                  \
@@ -1629,6 +1633,8 @@ int set_max_dynamic_lds(size_t bytes) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
     RT_ATTR1((render_kernel<true, true, true, false, 5, 8>))
     RT_ATTR1((render_kernel<true, true, true, false, 5, 16>))
+    RT_ATTR1((render_kernel<true, true, true, true, 5, 8>))
+    RT_ATTR1((render_kernel<true, true, true, true, 5, 16>))
     RT_ATTR1((render_kernel<true, true, true, false, 3, 8>))
     RT_ATTR1((render_kernel<true, true, true, false, 3, 16>))
     RT_ATTR1((render_kernel<true, true, true, false, 2, 8>))

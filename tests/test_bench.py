@@ -49,7 +49,12 @@ def test_flop_accounting_follows_survey_8d():
          "groups_visited": 30}
     s, bx, setup = b.executed_tests(c, lanes=64.0)
     assert s == 640 * 4 + 1000 * 16 and bx == 640 * 8 + 64 * 30 * 4 and setup == b.F_CULL_SETUP * 640
-    # range tables (the default): one window-box clip per query and window, one box test per candidate cluster
+    # uniform grid (the default): one bounds clip per query, one sphere test per list entry of the cells a lane visits
+    c = {"queries": 640, "cull_prefix": 4, "lane_clusters": 1800, "cull_cluster_size": 8, "cull_mode": 5, "cull_windows": 1,
+         "lane_cands": 450, "lane_groups": 470}
+    s, bx, setup = b.executed_tests(c, lanes=64.0)
+    assert s == 640 * 4 + 1800 and bx == 640 and setup == b.F_GRID_SETUP * 640 + b.F_GRID_ENTER * 470 + b.F_GRID_STEP * 450
+    # range tables: one window-box clip per query and window, one box test per candidate cluster
     c = {"queries": 640, "cull_prefix": 4, "lane_clusters": 1200, "cull_cluster_size": 8, "cull_mode": 3, "cull_windows": 1,
          "lane_cands": 2000, "lane_groups": 470}
     s, bx, setup = b.executed_tests(c, lanes=64.0)

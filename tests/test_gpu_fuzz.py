@@ -34,7 +34,7 @@ def test_random_schedules_equal_the_checker(rtmi, rtcheck, scenes_dir, fuzz_seed
         tile_rows = int(rng.choice([1, 3, 8, 8, 16]))
         stride = int(rng.integers(1, 6))
         tf = int(rng.integers(0, stride))
-        variant = int(rng.choice([0, 0, 0, 1, 64, 32, 40]))
+        variant = int(rng.choice([0, 0, 0, 1, 64, 32, 40, 128]))
         o = rtmi.Opts(seed=int(rng.integers(0, 2**31)), sample_first=first, sample_count=count, spp_chunk=chunk,
                       tile_rows=tile_rows, tile_first=tf, tile_stride=stride, variant=variant)
         rows = sc.shard_global_rows(o)

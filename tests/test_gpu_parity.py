@@ -132,8 +132,8 @@ def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir
     """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
     bit 1: unbatched sphere loop; bit 3: sphere table read through the scalar cache instead of
     LDS; bit 4: no AABB cluster culling (the reference's linear scan); bit 5: wave-level cluster votes;
-    bit 6: candidate clusters through the box hierarchy instead of the range tables.  Same bits as the
-    checker in every combination."""
+    bit 6: candidate clusters through the box hierarchy, bit 7: through the range tables, instead of the
+    uniform-grid walk (0, 1, 40).  Same bits as the checker in every combination."""
     for name, w, h, spp in (("rtiow", 72, 40, 6), ("mixed_emissive", 50, 30, 5)):
         sc = _scene(rtmi, scenes_dir, golden_dir, name)
         sc.override(width=w, height=h, spp=spp)
@@ -323,10 +323,10 @@ def test_axis_parallel_bounce_is_not_culled(rtmi, rtcheck):
     assert len(queries) == 1 and queries[0][3] == 0.0 and queries[0][7] == 1.0  # d.x == 0 exactly, and the ray hits
     assert abs(queries[0][6] - 0.9) < 1e-3                                      # the sphere at (1000, 0, 0), t = 4.5 / 5
     imgs = {}
-    for variant in (0, 1, 4, 32, 64, 16):
+    for variant in (0, 1, 4, 32, 64, 128, 16):
         imgs[variant] = _assert_same(rtmi, rtcheck, sc, variant=variant)
         assert np.all(imgs[variant][4, 4] == np.float32([4.0, 8.0, 12.0]))  # 4 spp x the lattice centre's light (1, 2, 3)
-    for variant in (0, 1, 4, 32, 64):
+    for variant in (0, 1, 4, 32, 64, 128):
         assert np.array_equal(imgs[variant], imgs[16])
 
 
@@ -341,6 +341,7 @@ def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
         _assert_same(rtmi, rtcheck, sc)
         _assert_same(rtmi, rtcheck, sc, variant=32)
         _assert_same(rtmi, rtcheck, sc, variant=64)
+        _assert_same(rtmi, rtcheck, sc, variant=128)
         vol = rtmi.Scene.new(64, 40, 3, 10)        # a volume
         vol.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
         vol.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
@@ -352,6 +353,7 @@ def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
         _assert_same(rtmi, rtcheck, vol)
         _assert_same(rtmi, rtcheck, vol, variant=40)
         _assert_same(rtmi, rtcheck, vol, variant=104)
+        _assert_same(rtmi, rtcheck, vol, variant=136)
     monkeypatch.delenv("RTMI_CLUSTER")
     assert rtmi.Scene.rtiow(5, 32, 18, 1, 5).count(rtmi.Opts()).cull_cluster_size == 8
     vol2 = rtmi.Scene.new(16, 16, 1, 3)
@@ -383,6 +385,9 @@ def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
     assert 0 < st.clusters_visited < 0.35 * st.wave_queries * st.cull_clusters
     # 4 big spheres are always tested; the 480 small ones make 60 clusters of 8 = one 64-cluster window
     assert st.cull_prefix == 4 and st.cull_cluster_size == 8 and st.cull_clusters == 60
+    # the default walks the uniform grid: fewer sphere tests per query than one 8-sphere cluster
+    assert st.cull_mode == 5 and 0 < st.lane_clusters < 8 * st.queries and 0 < st.lane_groups <= st.queries
+    st = sc.count(rtmi.Opts(seed=SEED, variant=128))
     assert st.cull_mode == 3 and st.cull_windows == 1 and 0 < st.lane_clusters <= st.lane_cands
     # a second scene seed, and the DNA frame (30 cylinders culled by their world-space boxes)
     sc2 = rtmi.Scene.rtiow(11, 960, 540, 16, 50)
@@ -426,8 +431,9 @@ def test_unpinned_edge_cases_on_device(rtmi, rtcheck):
 
 def test_big_sheet_uses_range_tables_over_many_windows(rtmi, rtcheck):
     """3000 small spheres spread over a ground sheet: 375 clusters = 6 windows of 64 clusters, each with its own range
-    tables; 48 KB of sphere records + 36 KB of tables go through global memory (variant 40).  Same bits as the flat
-    scan and the checker; the same scene forced into LDS (one workgroup per CU at that size) too."""
+    tables (variant 136: 48 KB of sphere records + 36 KB of tables through global memory; 128: the same forced into
+    LDS, one workgroup per CU at that size).  The default walks the grid instead (through global memory at this size).
+    Same bits as the flat scan and the checker, all of them."""
     sc = rtmi.Scene.new(96, 54, 2, 10)
     sc.camera((0, 9, 26), (0, 0, 0), (0, 1, 0), 40.0)
     sc.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
@@ -438,10 +444,14 @@ def test_big_sheet_uses_range_tables_over_many_windows(rtmi, rtcheck):
         r = float(rng.uniform(0.05, 0.15))
         sc.sphere((float(rng.uniform(-20, 20)), r, float(rng.uniform(-20, 20))), r, mats[i % len(mats)])
     st = sc.count(rtmi.Opts(seed=SEED))
+    assert st.cull_mode == 5 and st.lane_clusters > 0 and st.lane_groups > 0
+    st = sc.count(rtmi.Opts(seed=SEED, variant=136))
     assert st.cull_mode == 3 and st.cull_windows == 6 and st.cull_clusters == 375 and st.lane_cands >= st.lane_clusters > 0
     img = _assert_same(rtmi, rtcheck, sc)
     assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
-    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=1)))   # tables in LDS (90 KB per workgroup)
-    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=64)))  # the box hierarchy on the same clusters
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=1)))    # grid tables in LDS
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=136)))
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=128)))  # range tables in LDS (90 KB per workgroup)
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=64)))   # the box hierarchy on the same clusters
     with pytest.raises(rtmi.RtmiError, match="one window"):
         sc.render(rtmi.Opts(seed=SEED, variant=4))

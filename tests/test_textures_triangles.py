@@ -228,7 +228,7 @@ def _showcase(rtmi, tmp_path, w=72, h=45, spp=6):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 16, 40])
+@pytest.mark.parametrize("variant", [0, 16, 40, 128, 136])
 def test_textured_scene_bit_exact(rtmi, rtcheck, tmp_path, variant):
     sc = _showcase(rtmi, tmp_path)
     img = sc.render(rtmi.Opts(seed=SEED, variant=variant))

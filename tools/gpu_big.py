@@ -1,6 +1,7 @@
 """Scene-size sweep: N random small spheres over a ground sphere, default kernel (LDS tables or, above the
 threshold, global-memory tables) -- kernel time, which variant ran, and equality with the linear scan on
-a few rows.  RTMI_GLOBAL_TABLE_BYTES=<bytes> moves the threshold (read once per process)."""
+a few rows.  RTMI_GLOBAL_TABLE_BYTES=<bytes> moves the threshold (read once per process).
+usage: gpu_big.py [sizes] [variants]   e.g. gpu_big.py 1000,4000 0,64,128"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +9,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 rtmi = load_package()
 sizes = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1000", "2000", "4000", "8000", "20000", "100000"])]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 W, H, SPP = 1280, 720, 16
 for n in sizes:
     rng = np.random.default_rng(n)
@@ -21,13 +23,18 @@ for n in sizes:
     cen = rng.uniform(-half, half, (n, 3)); rad = rng.uniform(0.05, 0.2, n)
     for i in range(n):
         sc.sphere(tuple(cen[i]), float(rad[i]), mats[i % len(mats)])
-    ts = []
-    for rep in range(3):
-        st = rtmi.Stats(); img = sc.render(rtmi.Opts(seed=1), st); ts.append(st.kernel_ms)
-    cst = sc.count(rtmi.Opts(seed=1))
-    # a few rows against the linear scan (no culling): must be identical
-    o = rtmi.Opts(seed=1, tile_rows=4, tile_first=60, tile_stride=100000)
-    same = np.array_equal(sc.render(o), sc.render(rtmi.Opts(seed=1, tile_rows=4, tile_first=60, tile_stride=100000, variant=16))) if n <= 4000 else None
-    print(f"n={n}: {min(ts):.2f} ms ({W*H*SPP/min(ts)/1e3:.0f} Msamples/s), clusters {cst.cull_clusters} x {cst.cull_cluster_size}, "
-          f"wave cluster visits/query {cst.clusters_visited/max(1,cst.wave_queries):.1f}, groups passed/query {cst.groups_visited/max(1,cst.wave_queries):.1f}, "
-          f"rows equal linear scan: {same}", flush=True)
+    for variant in variants:
+        ts = []
+        try:
+            for rep in range(3):
+                st = rtmi.Stats(); img = sc.render(rtmi.Opts(seed=1, variant=variant), st); ts.append(st.kernel_ms)
+        except rtmi.RtmiError as e:
+            print(f"n={n} variant {variant}: {e}", flush=True)
+            continue
+        cst = sc.count(rtmi.Opts(seed=1, variant=variant))
+        # a few rows against the linear scan (no culling): must be identical
+        o = rtmi.Opts(seed=1, tile_rows=4, tile_first=60, tile_stride=100000, variant=variant)
+        same = np.array_equal(sc.render(o), sc.render(rtmi.Opts(seed=1, tile_rows=4, tile_first=60, tile_stride=100000, variant=16))) if n <= 4000 else None
+        print(f"n={n} variant {variant} (mode {cst.cull_mode}): {min(ts):.2f} ms ({W*H*SPP/min(ts)/1e3:.0f} Msamples/s), clusters {cst.cull_clusters} x {cst.cull_cluster_size}, "
+              f"wave cluster visits/query {cst.clusters_visited/max(1,cst.wave_queries):.1f}, groups passed/query {cst.groups_visited/max(1,cst.wave_queries):.1f}, "
+              f"lane tests/query {cst.lane_clusters/max(1,cst.queries):.2f}, rows equal linear scan: {same}", flush=True)

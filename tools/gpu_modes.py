@@ -19,7 +19,7 @@ if len(sys.argv) > 4 and sys.argv[4] == "child":
             st = rtmi.Stats(); img = sc.render(o, st); best = min(best, st.kernel_ms)
         crc = zlib.crc32(img.tobytes())
         line = f"cluster {os.environ.get('RTMI_CLUSTER')} variant {v}: {best:.2f} ms -> {1920*1080*spp/best/1e3:.0f} Msamples/s crc {crc:08x}"
-        if v in (0, 40, 64, 128, 136):
+        if v in (0, 1, 40, 64, 104, 128, 136):
             c = sc.count(o).as_dict()
             q, wq = c["queries"], max(1, c["wave_queries"])
             line += (f" | per query: cands {c['lane_cands']/q:.2f} clusters {c['lane_clusters']/q:.2f} windows {c['lane_groups']/q:.2f}"
