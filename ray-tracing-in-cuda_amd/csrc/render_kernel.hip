@@ -319,6 +319,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     // The loops of (5) cost max-over-lanes attempts each; as two loops (one inside the refill, one inside the shading)
     // they took 13 % of the frame (measured by cutting them out, RT_ABLATE=1).
     bool ended = false;  // this lane's path ended in step (6) of the previous iteration: its sample is added in (3)
+    // CULL == 5: ray parameter at which this lane's grid walk was cut short in the previous iteration (0: it was not);
+    // the walk goes on from there in this one
+    float t_res = 0.0f;
     for (;;) {
         tick(5);
         bool path_done = false;
@@ -508,6 +511,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 const float bx1 = fmaf((float)gnx, g_size.x, g_min.x) - shrink, by1 = fmaf((float)gny, g_size.y, g_min.y) - shrink,
                             bz1 = fmaf((float)gnz, g_size.z, g_min.z) - shrink;
                 blim = best_t * 1.0001f;
+                // a walk that was cut short goes on a few ulps past the cell boundary it stopped at: inside the next cell (the
+                // lists' margin of 0.004 cell covers the sliver), so that every resumption ends at a later boundary
+                const float t_from = t_res * 1.000002f;
                 bool live = false;
                 int ci = 0, k = 0, kend = 0;
                 uint32_t rem = 0;  // steps left before the ray leaves the grid: x | y << 8 | z << 16
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const float lx = (bx0 - ox) * bp.idx, ux = (bx1 - ox) * bp.idx;
                     const float ly = (by0 - oy) * bp.idy, uy = (by1 - oy) * bp.idy;
                     const float lz = (bz0 - oz) * bp.idz, uz = (bz1 - oz) * bp.idz;
-                    const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
+                    const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), t_from), fminf(lz, uz));
                     t_exit = fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), fmaxf(lz, uz));
                     live = !(tn > fminf(t_exit, blim));
                     if (live) {
@@ -541,15 +547,23 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                               (uint32_t)(dz > 0.0f ? gnz - 1 - iz : iz) << 16;
                         const uint32_t hdr = g_cells[ci];
                         k = (int)(hdr >> 12), kend = k + (int)((hdr >> cnt_shift) & 63u);
-                        if (COUNT) c_lane_groups++;
+                        if (COUNT && t_res == 0.0f) c_lane_groups++;
                     }
                 }
+                t_res = 0.0f;
                 // |size / d| per axis: what one step adds to the leave distance
                 const float dtx = g_size.x * fabsf(bp.idx), dty = g_size.y * fabsf(bp.idy), dtz = g_size.z * fabsf(bp.idz);
                 const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? gnx : -gnx, sz = dz > 0.0f ? gnx * gny : -(gnx * gny);
                 // cell by cell: the wave first drains the lists of the cells its lanes stand in (one sphere per lane and
                 // pass), then every lane steps (measured: 47.4 ms against 54.8 for one flattened loop in which a lane either
                 // tests or steps, RTIOW 256 spp)
+#ifndef RT_STEP_AT
+#define RT_STEP_AT 24  /* lanes that must be waiting before the wave runs a step pass while others still test (65: never) */
+#endif
+#ifndef RT_WALK_TAIL
+#define RT_WALK_TAIL 12     /* at most this many lanes still walking ...                                   (0: never cut) */
+#define RT_WALK_WAITING 32  /* ... and at least this many live lanes done: the stragglers go on next iteration */
+#endif
                 while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
                     while (__builtin_amdgcn_ballot_w64(k < kend) != 0ull) {
                         if (COUNT) c_clusters++;
@@ -559,14 +573,26 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                             if (COUNT) c_lane_clusters++;
                             RT_SPHERE_TEST(S, idx)
                         }
+                        if (RT_STEP_AT < 65 && (int)__popcll(__builtin_amdgcn_ballot_w64(live && !(k < kend))) >= RT_STEP_AT) break;
                     }
                     if (COUNT) c_groups++;
-                    if (live) {
+                    // The tail: a wave's walk lasts as long as its slowest lane's (11 test and 4 step passes for 2.8 tests
+                    // and 0.7 steps per lane).  When only a few lanes are still walking while most of the wave waits for
+                    // its shading, the stragglers stop at their next cell boundary and go on from there in the next
+                    // iteration, together with the new queries (the walk is front to back: nothing nearer than the
+                    // boundary was found, and whatever was found beyond it is found again in its own cell).
+                    const unsigned long long walking = __builtin_amdgcn_ballot_w64(live);
+                    const bool cut = RT_WALK_TAIL > 0 && (int)__popcll(walking) <= RT_WALK_TAIL &&
+                                     (int)__popcll(__builtin_amdgcn_ballot_w64(active) & ~walking) >= RT_WALK_WAITING;
+                    if (live && !(k < kend)) {
                         const float tnext = fminf(fminf(tmx, tmy), tmz);
                         const bool xle = tmx == tnext, yle = !xle && tmy == tnext;
                         const int sh = xle ? 0 : (yle ? 8 : 16);
                         if (tnext > fminf(t_exit, best_t * 1.0001f) || ((rem >> sh) & 255u) == 0u) {
                             live = false;
+                        } else if (cut && tnext > t_from) {
+                            live = false;
+                            t_res = tnext;
                         } else {
                             ci += xle ? sx : (yle ? sy : sz);
                             tmx += xle ? dtx : 0.0f, tmy += yle ? dty : 0.0f, tmz += (xle || yle) ? 0.0f : dtz;
@@ -1004,8 +1030,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     }
                 }
             }
+            // (a lane whose grid walk was cut short has no result yet: its query goes on in the next iteration)
+            const bool unfinished = CULL == 5 && t_res != 0.0f;
             if (COUNT) {
-                c_queries++;
+                if (!unfinished) c_queries++;
                 if ((int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) == lane) c_wave_queries++;
             }
 
@@ -1013,7 +1041,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             // ---- (2) the winner (ray_color body, main.cu:45-65 / main.cpp:22-38)
             // 1/|d| once per query (metal, dielectric and the sky all normalise the direction)
             inv_len = 1.0f / sqrtf(ra);
-            if (best_id >= 0) {
+            if (unfinished) {
+            } else if (best_id >= 0) {
                 // hit record of the winner only (the reference fills one per candidate)
                 if (best_id < ns) {
                     const float4 s = sph[best_id];
