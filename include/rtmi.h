@@ -277,7 +277,9 @@ typedef struct rt_stats {
     uint64_t lane_clusters;          /* culling: cluster boxes that passed, per LANE (what each ray needs) */
     uint64_t lane_groups;            /* culling: outer boxes that passed, per LANE; range tables: window boxes reached */
     uint64_t group_maxpop;           /* culling: max over lanes of needed clusters, summed over visited groups */
-    uint64_t query_maxpop;           /* culling: max over lanes of needed clusters, summed over wave-queries */
+    uint64_t query_maxpop;           /* culling: max over lanes of needed clusters, summed over wave-queries; grid: LANES whose
+                                        origin lies beyond the lists' reach and that scan every clustered sphere
+                                        (group_maxpop: lanes that walk the far tier of the lists) */
     uint64_t cycles[6];              /* shader-clock time per main-loop section, summed over waves: refill, prefix
                                         spheres, culled spheres + rects + cylinders, shading, accumulation, loop control */
     int32_t cull_prefix, cull_clusters, cull_groups, cull_cluster_size; /* table geometry */

@@ -547,9 +547,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                               (uint32_t)(dz > 0.0f ? gnz - 1 - iz : iz) << 16;
                         const uint32_t hdr = g_cells[ci];
                         k = (int)(hdr >> 12), kend = k + (int)((hdr >> cnt_shift) & 63u);
-                        if (COUNT && t_res == 0.0f) c_lane_groups++;
+                        if (COUNT && t_res == 0.0f) c_lane_groups++, c_group_maxpop += tier_far ? 1u : 0u;
                     }
                 }
+                if (COUNT && far_scan) c_query_maxpop++;
                 t_res = 0.0f;
                 // |size / d| per axis: what one step adds to the leave distance
                 const float dtx = g_size.x * fabsf(bp.idx), dty = g_size.y * fabsf(bp.idy), dtz = g_size.z * fabsf(bp.idz);

@@ -455,3 +455,50 @@ def test_big_sheet_uses_range_tables_over_many_windows(rtmi, rtcheck):
     assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=64)))   # the box hierarchy on the same clusters
     with pytest.raises(rtmi.RtmiError, match="one window"):
         sc.render(rtmi.Opts(seed=SEED, variant=4))
+
+
+def _cloud(rtmi, n, half, seed, w=64, h=40, spp=3, depth=12, r=(0.05, 0.25)):
+    sc = rtmi.Scene.new(w, h, spp, depth)
+    sc.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
+    rng = np.random.default_rng(seed)
+    mats = [sc.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(4)] + [sc.metal((0.8, 0.8, 0.8), 0.1), sc.dielectric(1.5)]
+    for i in range(n):
+        sc.sphere(rng.uniform(-half, half, 3), float(rng.uniform(*r)), mats[i % len(mats)])
+    return sc, mats
+
+
+def test_grid_list_tiers_and_the_scan_beyond_them(rtmi, rtcheck):
+    """The grid's cell lists are grown for ray origins near the cloud (near tier: within 1.5 cloud radii or the camera's
+    distance) and for origins up to 64 units / 8 cloud radii out (far tier); further out a lane scans every clustered
+    sphere.  A plane mirror sends the camera's rays back into a cloud of 300 spheres from 40 units away (far tier) or from
+    90 (beyond the lists' reach): every pixel equals the flat scan and the checker."""
+    for mirror_z, far_tier, beyond in ((-40.0, True, False), (-90.0, False, True)):
+        sc, mats = _cloud(rtmi, 300, 3.0, 31, w=80, h=50, spp=4)
+        sc.xy_rect(-300.0, 300.0, -300.0, 300.0, mirror_z, sc.metal((0.95, 0.95, 0.95), 0.0))
+        sc.camera((0.0, 2.0, 14.0), (0.0, 0.0, 0.0), (0, 1, 0), 40.0)
+        st = sc.count(rtmi.Opts(seed=SEED))
+        assert st.cull_mode == 5 and st.lane_groups > 0
+        if far_tier:
+            assert st.group_maxpop > 0, "no lane walked the far tier"
+        if beyond:
+            assert st.query_maxpop > 0, "no lane scanned from beyond the lists' reach"
+        img = _assert_same(rtmi, rtcheck, sc)
+        assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
+        assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=40)))
+        assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=1)))
+
+
+def test_scenes_without_a_grid_fall_back_to_the_cluster_search(rtmi, rtcheck):
+    """More than 63 spheres listed in one cell (a clump) leaves the scene without a grid: the default is then the range
+    tables (sheet) or the box hierarchy (volume), and an explicit grid variant is refused."""
+    sc, mats = _cloud(rtmi, 200, 4.0, 41)
+    rng = np.random.default_rng(42)
+    for i in range(90):  # the clump
+        sc.sphere(tuple(np.array([1.0, 1.0, 1.0]) + rng.uniform(-0.02, 0.02, 3)), 0.1, mats[i % len(mats)])
+    sc.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
+    st = sc.count(rtmi.Opts(seed=SEED))
+    assert st.cull_mode in (2, 3)
+    img = _assert_same(rtmi, rtcheck, sc)
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
+    with pytest.raises(rtmi.RtmiError, match="grid"):
+        sc.render(rtmi.Opts(seed=SEED, variant=1))
