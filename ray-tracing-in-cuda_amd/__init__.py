@@ -227,7 +227,7 @@ class Scene:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None:  # (module globals are already cleared when the interpreter shuts down)
             _lib.rt_scene_free(h)
             self._h = None
 

@@ -122,6 +122,7 @@ struct DevCounters {
     unsigned long long life_cycles, life_ticks;  // per-wave lifetime in shader cycles (s_memtime) and 100 MHz ticks, summed
     unsigned long long t_qe_min, t_qe_max;  // when a wave first found the queue empty
     unsigned int drain_hist[32];            // waves by time from queue-empty to exit, 50 us bins
+    unsigned long long occ_hist[2][17];     // wave-queries by live lanes (bins of 4; 16 = all 64), [0] while the queue has items, [1] after
     unsigned int qe_hist[1024];             // waves by time from their start to queue-empty, 64 us bins
     unsigned int exit_hist[1024];           // waves by time from their start to exit, 64 us bins
     unsigned long long cycles[6];  // shader-clock time per main-loop section, summed over waves

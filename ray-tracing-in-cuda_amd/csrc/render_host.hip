@@ -1045,6 +1045,10 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
                 fprintf(stderr, "queue-empty seen over %.1f us; first exit %.1f us after the first queue-empty; drain histogram (50 us bins):",
                         (double)(h.t_qe_max - h.t_qe_min) * 0.01, (double)(h.t_end_min - h.t_qe_min) * 0.01);
                 for (int i = 0; i < 32; ++i) fprintf(stderr, " %u", h.drain_hist[i]);
+                for (int e = 0; e < 2; ++e) {
+                    fprintf(stderr, "\nwave-queries by live lanes (bins of 4 lanes, last = all 64), %s:", e ? "after the wave found the queue empty" : "while the queue had items");
+                    for (int i = 0; i < 17; ++i) fprintf(stderr, " %llu", h.occ_hist[e][i]);
+                }
                 fprintf(stderr, "\nwaves by time from start to queue-empty (64 us bins, first nonzero bin on):");
                 int first = 0;
                 while (first < 1023 && !h.qe_hist[first]) ++first;

@@ -54,7 +54,7 @@
 // the flat-scan ablation kernels (CULL == 0) keep two register sets of sphere records in flight
 // an item is retired (its LDS accumulator flushed and reused) once at most this many of its paths are still alive
 #ifndef RT_ORPHAN_MAX
-#define RT_ORPHAN_MAX 12
+#define RT_ORPHAN_MAX 63
 #endif
 // CULL == 4: work-list entries a lane contributes per pass, and the list's capacity per wave
 #define RT_WL_PER_LANE 6
@@ -1035,7 +1035,11 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             const bool unfinished = CULL == 5 && t_res != 0.0f;
             if (COUNT) {
                 if (!unfinished) c_queries++;
-                if ((int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) == lane) c_wave_queries++;
+                const unsigned long long alive = __builtin_amdgcn_ballot_w64(true);
+                if ((int)__builtin_ctzll(alive) == lane) {
+                    c_wave_queries++;
+                    atomicAdd(&counters->occ_hist[queue_empty ? 1 : 0][__popcll(alive) >> 2], 1ull);
+                }
             }
 
             tick(2);
@@ -1225,9 +1229,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         }
         // The pool is handed out and idle lanes want the next item: retire the current one.  Its
         // accumulator is flushed for reuse and every path still alive becomes an orphan (three scattered 64-bit
-        // global atomics when it ends: 64-byte memory-side requests for 8 useful bytes each).  So the item is only
-        // retired once at most RT_ORPHAN_MAX paths are left: the idle lanes wait the two or three iterations that
-        // takes (paths last 2.7 queries on average, an item hundreds of iterations).
+        // global atomics when it ends: 64-byte memory-side requests for 8 useful bytes each).  RT_ORPHAN_MAX < 63 makes
+        // the idle lanes wait until at most that many paths are left; not waiting measures best (whole frame 147.3
+        // against 147.9 ms with 12, a 1/8 row shard 19.97 against 20.36 ms: its items are short).
         bool fetch = exhausted && !queue_empty;
         if (c_valid && idle != 0ull && fetch) {
             if (__popcll(~idle) <= RT_ORPHAN_MAX) {
