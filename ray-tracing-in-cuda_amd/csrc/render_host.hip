@@ -908,6 +908,16 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         return RT_ERR_LIMIT;
     }
     const size_t lds_bytes = ((variant & 8u) ? 0 : hot_bytes) + acc_lds + wl_lds;
+    static const bool debug_layout = getenv("RTMI_DEBUG_LAYOUT") != nullptr;
+    if (debug_layout) {
+        const float *g = cache.image.data() + (size_t)P.off_grid * 4;
+        int gn[3];
+        memcpy(gn, g + 12, sizeof gn);
+        fprintf(stderr, "variant %u: LDS %zu bytes per workgroup (tables %zu); %d prefix slots, %d clusters of %d; grid %d x %d x %d = %d cells, "
+                "cell %.3f x %.3f x %.3f, %d list entries (vec4 records: cells %d, lists %d)\n",
+                variant, lds_bytes, (variant & 8u) ? (size_t)0 : hot_bytes, P.np, P.ncl, P.cluster, gn[0], gn[1], gn[2], P.grid_cells,
+                g[8], g[9], g[10], (P.hot_vec4_grid - P.off_grid_items) * 8, P.off_grid_items - P.off_grid_cells, P.hot_vec4_grid - P.off_grid_items);
+    }
     if (lds_bytes > 160 * 1024) {
         set_error("kernel variant %u keeps the scene tables in LDS and this scene needs %zu bytes per workgroup "
                   "(limit 163840); use the default variant",

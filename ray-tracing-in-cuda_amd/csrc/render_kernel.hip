@@ -54,7 +54,7 @@
 // the flat-scan ablation kernels (CULL == 0) keep two register sets of sphere records in flight
 // an item is retired (its LDS accumulator flushed and reused) once at most this many of its paths are still alive
 #ifndef RT_ORPHAN_MAX
-#define RT_ORPHAN_MAX 63
+#define RT_ORPHAN_MAX 32
 #endif
 // CULL == 4: work-list entries a lane contributes per pass, and the list's capacity per wave
 #define RT_WL_PER_LANE 6
@@ -1229,9 +1229,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         }
         // The pool is handed out and idle lanes want the next item: retire the current one.  Its
         // accumulator is flushed for reuse and every path still alive becomes an orphan (three scattered 64-bit
-        // global atomics when it ends: 64-byte memory-side requests for 8 useful bytes each).  RT_ORPHAN_MAX < 63 makes
-        // the idle lanes wait until at most that many paths are left; not waiting measures best (whole frame 147.3
-        // against 147.9 ms with 12, a 1/8 row shard 19.97 against 20.36 ms: its items are short).
+        // global atomics when it ends: 64-byte memory-side requests for 8 useful bytes each).  So the item is only
+        // retired once at most RT_ORPHAN_MAX paths are left, the idle lanes wait meanwhile.  Measured 12 / 32 / 63 (never
+        // wait): whole frame 147.9 / 147.9 / 147.3 ms, a 1/8 row shard (short items) 20.36 / 20.11 / 19.97 ms, HBM writes
+        // of the launch 1.16 GB / - / 2.0 GB.
         bool fetch = exhausted && !queue_empty;
         if (c_valid && idle != 0ull && fetch) {
             if (__popcll(~idle) <= RT_ORPHAN_MAX) {
