@@ -76,6 +76,7 @@ struct RenderParams {
     // chunk-major queue: n_big chunks of spp_chunk, n_med chunks of q_med, then chunks of q_small to the end
     // (guided self-scheduling: the later an item is handed out, the shorter it is); num_chunks = total
     int32_t sample_first, sample_count, spp_chunk, num_chunks, n_big, n_med, q_med, q_small;
+    int32_t orphan_max;      // an item is retired once at most this many of its paths are alive (render_kernel.hip)
     uint32_t seed_lo, seed_hi;
     // scene image
     int32_t ns, nr, nc, nm;

@@ -732,8 +732,10 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
     static const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob, read once: 0 = off
     static const double tail_factor = getenv("RTMI_TAIL_FACTOR") ? atof(getenv("RTMI_TAIL_FACTOR")) : 12.0;  // measured at 7 waves/SIMD: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms, a 1/8 shard 33.7 / 33.4 / 32.0 / 32.2 ms
+    static const int tail_div = getenv("RTMI_TAIL_DIV") ? std::max(2, atoi(getenv("RTMI_TAIL_DIV"))) : 4;  // big : medium item length
+    static const int orphan_env = getenv("RTMI_ORPHAN_MAX") ? atoi(getenv("RTMI_ORPHAN_MAX")) : -1;
     int n_big = sample_count / spp_chunk, n_med = 0, q_med = spp_chunk, q_small = spp_chunk;
-    int num_chunks;
+    int num_chunks, orphan_max = 12;
     {
         const long long tiles = (long long)((s.width + 7) / 8) * ((sh.local_rows + 7) / 8);
         const double r = 256.0 * 4 * RT_WAVES_PER_SIMD / (double)std::max(1LL, tiles);
@@ -743,7 +745,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             const int n_split = std::min(n_big, std::max(1, (int)std::ceil(tail_factor * r)));  // big chunks given up
             n_big -= n_split;
             rest += n_split * spp_chunk;
-            q_med = std::max(4, spp_chunk / 4);
+            q_med = std::max(4, spp_chunk / tail_div);
             q_small = std::max(4, q_med / 4);
             int small_samples = 0;
             if (r >= 0.5 && q_small < q_med)  // few tiles per wave: a run of small items as well
@@ -755,6 +757,8 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         }
         const int after_med = rest - n_med * q_med;
         num_chunks = n_big + n_med + (after_med + q_small - 1) / q_small;
+        // orphans: waiting for an item's last paths costs short items more (render_kernel.hip, step 4)
+        orphan_max = orphan_env >= 0 ? std::min(63, orphan_env) : (r >= 0.5 ? 63 : 12);
     }
     if (sample_first < 0) {
         set_error("sample_first must be >= 0");
@@ -858,6 +862,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     P.sample_first = sample_first, P.sample_count = sample_count;
     P.spp_chunk = spp_chunk, P.num_chunks = num_chunks;
     P.n_big = n_big, P.n_med = n_med, P.q_med = q_med, P.q_small = q_small;
+    P.orphan_max = orphan_max;
     uint64_t seed = o ? o->seed : 0;
     P.seed_lo = (uint32_t)seed, P.seed_hi = (uint32_t)(seed >> 32);
     P.tiles_x = (s.width + 7) / 8;

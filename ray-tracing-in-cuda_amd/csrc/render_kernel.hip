@@ -52,10 +52,6 @@
 #define RT_WAVES_PER_SIMD 7
 #endif
 // the flat-scan ablation kernels (CULL == 0) keep two register sets of sphere records in flight
-// an item is retired (its LDS accumulator flushed and reused) once at most this many of its paths are still alive
-#ifndef RT_ORPHAN_MAX
-#define RT_ORPHAN_MAX 32
-#endif
 // CULL == 4: work-list entries a lane contributes per pass, and the list's capacity per wave
 #define RT_WL_PER_LANE 6
 #define RT_WL_CAP (64 * RT_WL_PER_LANE)
@@ -1228,14 +1224,14 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
         }
         // The pool is handed out and idle lanes want the next item: retire the current one.  Its
-        // accumulator is flushed for reuse and every path still alive becomes an orphan (three scattered 64-bit
-        // global atomics when it ends: 64-byte memory-side requests for 8 useful bytes each).  So the item is only
-        // retired once at most RT_ORPHAN_MAX paths are left, the idle lanes wait meanwhile.  Measured 12 / 32 / 63 (never
-        // wait): whole frame 147.9 / 147.9 / 147.3 ms, a 1/8 row shard (short items) 20.36 / 20.11 / 19.97 ms, HBM writes
-        // of the launch 1.16 GB / - / 2.0 GB.
+        // accumulator is flushed for reuse and every path still alive becomes an orphan (three 64-bit global atomics
+        // when it ends: one more dirty 64-byte line for 24 useful bytes).  So the item is only retired once at most
+        // P.orphan_max paths are left, the idle lanes wait meanwhile.  Measured 12 / 32 / 63 (never wait): whole frame
+        // 147.9 / 147.9 / 147.3 ms and 1.16 / - / 2.0 GB of HBM writes, a 1/8 row shard (short items) 20.36 / 20.11 /
+        // 19.97 ms: the host sets 12 for launches with many tiles per wave and 63 for small ones.
         bool fetch = exhausted && !queue_empty;
         if (c_valid && idle != 0ull && fetch) {
-            if (__popcll(~idle) <= RT_ORPHAN_MAX) {
+            if ((int)__popcll(~idle) <= P.orphan_max) {
                 if (active && slot == -2) slot = (c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7);
                 flush_tile(c_acc, c_x0, c_band);
                 c_valid = false;
