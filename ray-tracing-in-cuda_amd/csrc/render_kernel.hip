@@ -66,6 +66,10 @@
 #ifndef RT_WAVES_LINEAR
 #define RT_WAVES_LINEAR RT_WAVES_PER_SIMD
 #endif
+// 1: the candidates of the prefix records 1..3 of a group share one resolve block (render_kernel, RT_SPHERE_PARK)
+#ifndef RT_PREFIX_PARK
+#define RT_PREFIX_PARK 1
+#endif
 
 namespace rtmi {
 
@@ -103,6 +107,29 @@ __device__ __forceinline__ float rng_pm1(LaneRng &r) {  // random_double(-1, 1):
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
     return fmaf(ax, bx, fmaf(ay, by, az * bz));
+}
+
+// IEEE-correct fp32 square root, bit for bit what sqrtf() returns.  hipcc expands sqrtf() to v_sqrt_f32 (1 ulp) plus the
+// one-step correction below, wrapped in a scaling for arguments below 2^-96 (v_sqrt_f32 flushes denormals) and a fix-up for
+// 0 and inf: 17 instructions.  The arguments of this kernel (discriminants, squared lengths) are ordinary numbers, so the
+// wrapping only runs -- through sqrtf() itself -- when some lane of the wave really holds such an argument: 11 instructions
+// otherwise.  The kernel takes ~10 square roots per iteration of its main loop.
+#ifndef RT_FAST_SQRT
+#define RT_FAST_SQRT 1
+#endif
+__device__ __forceinline__ float rt_sqrtf(float x) {
+#if RT_FAST_SQRT
+    // [2^-96, inf): one unsigned compare on the bit pattern (negative numbers and NaN fall outside as well)
+    if (__builtin_expect((uint32_t)(__float_as_uint(x) - 0x0f800000u) >= (0x7f800000u - 0x0f800000u), 0)) return sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = fmaf(-s_dn, s, x), r_up = fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return r;
+#else
+    return sqrtf(x);
+#endif
 }
 
 // checker_texture::value, texture.cuh:44-52: sign of sin(10x)sin(10y)sin(10z) as the
@@ -347,7 +374,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const unsigned long long em = __builtin_amdgcn_ballot_w64(true);
                     if ((int)__builtin_ctzll(em) == lane) c_cand_wave++;
                 }
-                const float sq = sqrtf(disc);
+                const float sq = rt_sqrtf(disc);
                 float root = (-hb - sq) * rinv_a;
                 if (root < kTMin || best_t < root) root = (-hb + sq) * rinv_a;
                 if (!(root < kTMin || best_t < root)) {
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 float tnx = r0.w, tny = r1.w, tnz = r2.w;
                 float ocn = dot3(ox - r0.x, oy - r0.y, oz - r0.z, tnx, tny, tnz);
                 if (ocn < 0.0f) tnx = -tnx, tny = -tny, tnz = -tnz, ocn = -ocn;
-                const float a = sqrtf(ra);
+                const float a = rt_sqrtf(ra);
                 const float theta = dot3(dx, dy, dz, tnx, tny, tnz) / a;
                 if (!(theta < 0.0f)) return false;
                 rix = ox - ((dx / a) * ocn) / theta;
@@ -385,14 +412,41 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
         if (__builtin_expect(cand, 0)) resolve(IDX, hb, disc);                                 \
     }
+            // the same test with the candidate PARKED in (p_idx, p_hb, p_disc) instead of resolved on the spot: the cold block
+            // (IEEE sqrt, both roots, range and tie rules: ~45 instructions) runs once for the candidates of several
+            // records.  The closest hit does not depend on the order in which candidates are resolved (a candidate's root
+            // is its smallest one >= t_min, accepted while it is <= best_t: the outcome is the minimum over candidates, ties
+            // by list index), so parking is free to reorder.  A lane that finds a second candidate resolves the first there.
+#define RT_SPHERE_PARK(S, IDX)                                                                 \
+    {                                                                                          \
+        const float ocx = ox - S.x, ocy = oy - S.y, ocz = oz - S.z;                            \
+        const float hb = dot3(ocx, ocy, ocz, dx, dy, dz);                                      \
+        const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -S.w)));                 \
+        const float disc = fmaf(hb, hb, -(ra * cc));                                           \
+        const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
+        if (__builtin_expect(cand, 0)) {                                                       \
+            if (p_idx >= 0) resolve(p_idx, p_hb, p_disc);                                      \
+            p_idx = IDX, p_hb = hb, p_disc = disc;                                             \
+        }                                                                                      \
+    }
             if (active) {
-            // the always-tested prefix (big spheres), four records at a time
+            // the always-tested prefix (big spheres, largest first), four records at a time: the first one -- in RTIOW the
+            // ground, a candidate for half of the lanes -- is resolved at once, the other three share one resolve
             for (int i = 0; i < P.np; i += 4) {
                 const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
                 RT_SPHERE_TEST(s0, i)
+#if RT_PREFIX_PARK
+                int p_idx = -1;
+                float p_hb = 0.0f, p_disc = 0.0f;
+                RT_SPHERE_PARK(s1, i + 1)
+                RT_SPHERE_PARK(s2, i + 2)
+                RT_SPHERE_PARK(s3, i + 3)
+                if (p_idx >= 0) resolve(p_idx, p_hb, p_disc);
+#else
                 RT_SPHERE_TEST(s1, i + 1)
                 RT_SPHERE_TEST(s2, i + 2)
                 RT_SPHERE_TEST(s3, i + 3)
+#endif
             }
             if (!CULL) {
                 // flat scan (the reference's hittable_list loop) of every cluster's CSIZE records (clusters are
@@ -867,7 +921,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                                     float hb, disc;
                                     terms(cs[h], hb, disc);
                                     if (COUNT) c_cand++;
-                                    const float sq = sqrtf(disc);
+                                    const float sq = rt_sqrtf(disc);
                                     float root = (-hb - sq) * frinv;
                                     if (root < kTMin || lbt < root) root = (-hb + sq) * frinv;
                                     if (!(root < kTMin || lbt < root)) {
@@ -948,7 +1002,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 const float qc = fmaf(oox, oox, fmaf(ooy, ooy, -pr.x));
                 const float delta = fmaf(qb, qb, -((4.0f * qa) * qc));
                 if (!(delta < 0.0f)) {
-                    const float sq = sqrtf(delta);
+                    const float sq = rt_sqrtf(delta);
                     float t0 = (-0.5f * (qb - sq)) / qa;
                     float t1 = (-0.5f * (qb + sq)) / qa;
                     if (t0 > t1) {
@@ -1041,7 +1095,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             tick(2);
             // ---- (2) the winner (ray_color body, main.cu:45-65 / main.cpp:22-38)
             // 1/|d| once per query (metal, dielectric and the sky all normalise the direction)
-            inv_len = 1.0f / sqrtf(ra);
+            inv_len = 1.0f / rt_sqrtf(ra);
             if (unfinished) {
             } else if (best_id >= 0) {
                 // hit record of the winner only (the reference fills one per candidate)
@@ -1078,7 +1132,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const float ody = fmaf(r1.x, dx, fmaf(r1.y, dy, r1.z * dz));
                     const float odz = fmaf(r2.x, dx, fmaf(r2.y, dy, r2.z * dz));
                     const float opx = fmaf(best_t, odx, oox), opy = fmaf(best_t, ody, ooy), opz = fmaf(best_t, odz, ooz);
-                    const float len = sqrtf(fmaf(opx, opx, opy * opy));
+                    const float len = rt_sqrtf(fmaf(opx, opx, opy * opy));
                     const float onx = opx / len, ony = opy / len;
                     px = fmaf(m0.x, opx, fmaf(m0.y, opy, fmaf(m0.z, opz, m0.w)));
                     py = fmaf(m1.x, opx, fmaf(m1.y, opy, fmaf(m1.z, opz, m1.w)));
@@ -1143,13 +1197,13 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         float cx, cy, cz, ex, ey, ez;
                         cross3(a1x, a1y, a1z, a2x, a2y, a2z, cx, cy, cz);
                         cross3(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z, r2.x - r1.x, r2.y - r1.y, r2.z - r1.z, ex, ey, ez);
-                        const float w1 = sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+                        const float w1 = rt_sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / rt_sqrtf(dot3(ex, ey, ez, ex, ey, ez));
                         cross3(a1x, a1y, a1z, a3x, a3y, a3z, cx, cy, cz);
                         cross3(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z, r1.x - r2.x, r1.y - r2.y, r1.z - r2.z, ex, ey, ez);
-                        const float w2 = sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+                        const float w2 = rt_sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / rt_sqrtf(dot3(ex, ey, ez, ex, ey, ez));
                         cross3(a3x, a3y, a3z, a2x, a2y, a2z, cx, cy, cz);
                         cross3(r0.x - r2.x, r0.y - r2.y, r0.z - r2.z, r0.x - r1.x, r0.y - r1.y, r0.z - r1.z, ex, ey, ez);
-                        const float w3 = sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+                        const float w3 = rt_sqrtf(dot3(cx, cy, cz, cx, cy, cz)) / rt_sqrtf(dot3(ex, ey, ez, ex, ey, ez));
                         const float4 c0 = image[P.off_tri_cold + 2 * k], c1 = image[P.off_tri_cold + 2 * k + 1];
                         tu = fmaf(c1.z, w3, fmaf(c1.x, w2, c0.z * w1));
                         tv = fmaf(c1.w, w3, fmaf(c1.y, w2, c0.w * w1));
@@ -1345,7 +1399,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 float at_r, at_g, at_b;        // attenuation
                 bool scattered = true;
                 if (kind <= MK_LAMBERT_IMAGE) {  // lambertian::scatter, material.h:25-35
-                    const float inv = 1.0f / sqrtf(sl2);
+                    const float inv = 1.0f / rt_sqrtf(sl2);
                     ndx = nx + inv * sx, ndy = ny + inv * sy, ndz = nz + inv * sz;
                     const float eps = 1e-8f;
                     if (fabsf(ndx) < eps && fabsf(ndy) < eps && fabsf(ndz) < eps) ndx = nx, ndy = ny, ndz = nz;
@@ -1364,7 +1418,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const float ux = inv_len * dx, uy = inv_len * dy, uz = inv_len * dz;
                     const float udn = dot3(ux, uy, uz, nx, ny, nz);
                     const float cos_t = fminf(-udn, 1.0f);
-                    const float sin_t = sqrtf(fmaf(-cos_t, cos_t, 1.0f));
+                    const float sin_t = rt_sqrtf(fmaf(-cos_t, cos_t, 1.0f));
                     bool refl = ratio * sin_t > 1.0f;
                     if (!refl) {
                         const float r0 = front ? q0.w : q1.w;
@@ -1380,7 +1434,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         const float ppx = ratio * fmaf(cos_t, nx, ux);
                         const float ppy = ratio * fmaf(cos_t, ny, uy);
                         const float ppz = ratio * fmaf(cos_t, nz, uz);
-                        const float kk = -sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
+                        const float kk = -rt_sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
                         ndx = fmaf(kk, nx, ppx), ndy = fmaf(kk, ny, ppy), ndz = fmaf(kk, nz, ppz);
                     }
                     at_r = at_g = at_b = 1.0f;
