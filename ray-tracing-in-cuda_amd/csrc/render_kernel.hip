@@ -70,6 +70,10 @@
 #ifndef RT_PREFIX_PARK
 #define RT_PREFIX_PARK 1
 #endif
+// 1: the grid walk tests two entries of a cell's list per pass
+#ifndef RT_WALK_PAIR
+#define RT_WALK_PAIR 1
+#endif
 
 namespace rtmi {
 
@@ -618,12 +622,32 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
                     while (__builtin_amdgcn_ballot_w64(k < kend) != 0ull) {
                         if (COUNT) c_clusters++;
+#if RT_WALK_PAIR
+                        // two list entries per pass: both index reads, then both record reads, are in flight together, and a
+                        // cell's list costs the wave ceil(n / 2) passes (each a dependent LDS round trip, exec-mask
+                        // bookkeeping and a taken branch) instead of n.  A list of odd length reads the never-hit slot
+                        // behind the first cluster for its second half.
+                        if (k < kend) {
+                            const int idx = (int)g_items[k];
+                            const int j_raw = (int)g_items[k + 1];  // (one entry past the list at worst: the next list, or whatever follows the lists in LDS / in the scene image)
+                            const int jdx = k + 1 < kend ? j_raw : P.np + CSIZE;
+                            if (COUNT) c_lane_clusters += k + 1 < kend ? 2u : 1u;
+                            k += 2;
+                            const float4 S = sph[idx], T = sph[jdx];
+                            int p_idx = -1;
+                            float p_hb = 0.0f, p_disc = 0.0f;
+                            RT_SPHERE_PARK(S, idx)
+                            RT_SPHERE_PARK(T, jdx)
+                            if (p_idx >= 0) resolve(p_idx, p_hb, p_disc);
+                        }
+#else
                         if (k < kend) {
                             const int idx = (int)g_items[k++];
                             const float4 S = sph[idx];
                             if (COUNT) c_lane_clusters++;
                             RT_SPHERE_TEST(S, idx)
                         }
+#endif
                         if (RT_STEP_AT < 65 && (int)__popcll(__builtin_amdgcn_ballot_w64(live && !(k < kend))) >= RT_STEP_AT) break;
                     }
                     if (COUNT) c_groups++;
