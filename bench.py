@@ -260,10 +260,18 @@ def main():
 
 
 def _git_head():
+    """HEAD of this checkout; on a GPU box (a snapshot without .git) the value build() recorded in BUILD_HEAD."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                              timeout=10).stdout.strip() or None
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip()
+        if head:
+            return head
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "ray-tracing-in-cuda_amd", "BUILD_HEAD")) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 

@@ -74,6 +74,16 @@
 #ifndef RT_WALK_PAIR
 #define RT_WALK_PAIR 1
 #endif
+// candidate predicate of a sphere test: a real root that is not behind the origin.  1: evaluated without short-circuit
+// (three compares, one branch) instead of as two nested branches -- measured 146.5 against 145.5 ms, so 0
+#ifndef RT_CAND_FLAT
+#define RT_CAND_FLAT 0
+#endif
+#if RT_CAND_FLAT
+#define RT_CAND(disc, hb, cc) ((int)!((disc) < 0.0f) & (int)!((int)((hb) >= 0.0f) & (int)((cc) >= 0.0f)))
+#else
+#define RT_CAND(disc, hb, cc) (!((disc) < 0.0f) && !((hb) >= 0.0f && (cc) >= 0.0f))
+#endif
 
 namespace rtmi {
 
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         const float hb = dot3(ocx, ocy, ocz, dx, dy, dz);                                      \
         const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -S.w)));                 \
         const float disc = fmaf(hb, hb, -(ra * cc));                                           \
-        const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
+        const bool cand = RT_CAND(disc, hb, cc);                                                \
         if (__builtin_expect(cand, 0)) resolve(IDX, hb, disc);                                 \
     }
             // the same test with the candidate PARKED in (p_idx, p_hb, p_disc) instead of resolved on the spot: the cold block
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         const float hb = dot3(ocx, ocy, ocz, dx, dy, dz);                                      \
         const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -S.w)));                 \
         const float disc = fmaf(hb, hb, -(ra * cc));                                           \
-        const bool cand = !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);                       \
+        const bool cand = RT_CAND(disc, hb, cc);                                                \
         if (__builtin_expect(cand, 0)) {                                                       \
             if (p_idx >= 0) resolve(p_idx, p_hb, p_disc);                                      \
             p_idx = IDX, p_hb = hb, p_disc = disc;                                             \
@@ -613,10 +623,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 // pass), then every lane steps (measured: 47.4 ms against 54.8 for one flattened loop in which a lane either
                 // tests or steps, RTIOW 256 spp)
 #ifndef RT_STEP_AT
-#define RT_STEP_AT 24  /* lanes that must be waiting before the wave runs a step pass while others still test (65: never) */
+#define RT_STEP_AT 16  /* lanes that must be waiting before the wave runs a step pass while others still test (65: never; 16 / 24 / 32 / 65: 145.4 / 146.0 / 145.8 / 147.9 ms) */
 #endif
 #ifndef RT_WALK_TAIL
-#define RT_WALK_TAIL 12     /* at most this many lanes still walking ...                                   (0: never cut) */
+#define RT_WALK_TAIL 20     /* at most this many lanes still walking ...            (0: never cut; 0 / 8 / 12 / 20: 149.0 / 146.5 / 146.0 / 145.0 ms) */
 #define RT_WALK_WAITING 32  /* ... and at least this many live lanes done: the stragglers go on next iteration */
 #endif
                 while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
