@@ -96,6 +96,7 @@ struct RenderParams {
     // count), items (16-bit sphere slots); grid_cells == 0: the scene has no grid (no clustered spheres, or a cell with
     // more than 255 spheres)
     int32_t off_grid, off_grid_cells, off_grid_items, grid_cells;
+    int32_t grid_sheet;      // 1: the grid is one cell high (ny == 1): the walk steps along x and z only (CULL == 6)
     int32_t hot_vec4_grid;   // float4 count of the hot part through the grid tables (what the grid-walk kernel stages)
     int32_t hot_vec4_tables; // float4 count of the hot part including the range tables (what the range-table kernel stages)
     float cull_extent1;      // 1 + max |coordinate| of the clustered spheres (per-lane box margin, see packer)

@@ -332,6 +332,7 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         if (!ok) grid_cells.clear(), grid_items.clear(), grid_n[0] = grid_n[1] = grid_n[2] = 0;
     }
     L.grid_cells = (int)grid_cells.size();
+    L.grid_sheet = (!grid_cells.empty() && grid_n[1] == 1) ? 1 : 0;
     L.off_grid = off;  // 4 records {min.xyz, ob_near^2} {1/size.xyz, ob_far^2} {size.xyz, shrink} {nx, ny, nz, -}, then cells, then items
     off += 4;
     L.off_grid_cells = off;
@@ -876,7 +877,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // (each candidate search stages the part of the hot tables it reads)
     auto hot_bytes_of = [&](unsigned v) {
         const int mode = variant_cull_mode(v);
-        return (size_t)(mode == 5 ? P.hot_vec4_grid : ((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4)) * 16;
+        return (size_t)((mode == 5 || mode == 6) ? P.hot_vec4_grid : ((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4)) * 16;
     };
     static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
                                                                              : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;
@@ -885,9 +886,18 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // (65536 sphere slots or more, or a clump of more than 63 in one cell) keep round 2's choice: the range tables -- the
     // clusters a ray segment's BOUNDING BOX touches, sharp where the spheres lie on a sheet or are few -- and the box
     // hierarchy (bit 6) where they fill a volume.
+    // (variant 2 is variant 0 for a grid that is one cell high: a walk along x and z only; the counting kernel and the
+    //  builds with triangles / image textures only exist for the 3-D walk, whose cells and tests are the same)
+    static const bool no_sheet = getenv("RTMI_NO_SHEET") != nullptr;  // A/B knob
+    if (variant == 2 && (count || ext)) variant = 0;
+    if (variant == 2 && !P.grid_sheet) {
+        set_error("kernel variant 2 walks a grid that is one cell high, which this scene does not have");
+        return RT_ERR_LIMIT;
+    }
     if (variant == 0) {
         if (P.grid_cells > 0 || P.ncl == 0) {
             if (hot_bytes_of(0) > global_threshold) variant = 40;
+            else if (P.grid_sheet && !count && !ext && !no_sheet) variant = 2;
         } else {
             const int n_axes = (P.rt_axes & 1) + ((P.rt_axes >> 1) & 1) + ((P.rt_axes >> 2) & 1);
             variant = (n_axes == 3 && P.ncl > 16 && !ext) ? 64 : 128;  // (no EXT build of the box hierarchy)
@@ -896,7 +906,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     }
     if (variant == 64 && hot_bytes_of(64) > global_threshold) variant = 104;
     size_t hot_bytes = hot_bytes_of(variant);
-    if (variant_cull_mode(variant) == 5 && P.grid_cells == 0 && P.ncl > 0) {
+    if ((variant_cull_mode(variant) == 5 || variant_cull_mode(variant) == 6) && P.grid_cells == 0 && P.ncl > 0) {
         set_error("kernel variant %u walks the uniform grid, which this scene does not have (more than 65535 sphere slots, "
                   "or more than 63 spheres in one cell)", variant);
         return RT_ERR_LIMIT;

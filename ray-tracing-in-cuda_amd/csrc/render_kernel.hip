@@ -234,7 +234,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                                                      DevCounters *__restrict__ counters) {
     extern __shared__ float4 lds[];
     // stage the hot tables (hittable_list contents) into LDS
-    const int staged = SCALAR ? 0 : (CULL == 5 ? P.hot_vec4_grid : ((CULL == 3 || CULL == 4) ? P.hot_vec4_tables : P.hot_vec4));
+    // CULL == 6 is CULL == 5 for a grid that is one cell high (a sheet of spheres on the ground: RTIOW): the walk has no y axis
+    constexpr bool GRID = CULL == 5 || CULL == 6, SHEET = CULL == 6;
+    const int staged = SCALAR ? 0 : (GRID ? P.hot_vec4_grid : ((CULL == 3 || CULL == 4) ? P.hot_vec4_tables : P.hot_vec4));
     for (int i = threadIdx.x; i < staged; i += 256) lds[i] = image[i];
     // per-wave tile accumulator of the current work item: 64 pixels x rgb, 64-bit fixed point
     unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + staged);
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             };
             unsigned long long cand4 = 0ull;  // CULL == 4: this lane's candidate clusters (one window)
             if (active) {
-            if (CULL == 5) {
+            if (GRID) {
                 // ---- uniform grid, 3-D DDA per lane (the default).  The clustered spheres are listed in the cells
                 // their (error-grown, see the packer) boxes touch; a lane walks the cells its ray crosses in the order it
                 // crosses them and tests what they list, so the nearest hit ends the walk: a cell is only entered while
@@ -599,15 +601,18 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         // the cell of the entry point
                         const float px = fmaf(tn, dx, ox), py = fmaf(tn, dy, oy), pz = fmaf(tn, dz, oz);
                         const int ix = min(max((int)floorf((px - g_min.x) * g_inv.x), 0), gnx - 1);
-                        const int iy = min(max((int)floorf((py - g_min.y) * g_inv.y), 0), gny - 1);
+                        // (SHEET: one layer of cells.  A ray that leaves it through the top or the bottom ends its walk at t_exit,
+                        // the exit from the grid's bounds, which comes no later than the layer's own faces; so the walk needs
+                        // neither a y cell index nor a y leave distance, and visits the cells the 3-D walk would visit)
+                        const int iy = SHEET ? 0 : min(max((int)floorf((py - g_min.y) * g_inv.y), 0), gny - 1);
                         const int iz = min(max((int)floorf((pz - g_min.z) * g_inv.z), 0), gnz - 1);
-                        ci = (iz * gny + iy) * gnx + ix;
+                        ci = SHEET ? iz * gnx + ix : (iz * gny + iy) * gnx + ix;
                         // ray parameter at which the ray leaves the cell along each axis (a component of exactly 0
                         // never leaves), and how many steps are left before it leaves the grid
                         tmx = dx == 0.0f ? INFINITY : (fmaf((float)(ix + (dx > 0.0f ? 1 : 0)), g_size.x, g_min.x) - ox) * bp.idx;
-                        tmy = dy == 0.0f ? INFINITY : (fmaf((float)(iy + (dy > 0.0f ? 1 : 0)), g_size.y, g_min.y) - oy) * bp.idy;
+                        if (!SHEET) tmy = dy == 0.0f ? INFINITY : (fmaf((float)(iy + (dy > 0.0f ? 1 : 0)), g_size.y, g_min.y) - oy) * bp.idy;
                         tmz = dz == 0.0f ? INFINITY : (fmaf((float)(iz + (dz > 0.0f ? 1 : 0)), g_size.z, g_min.z) - oz) * bp.idz;
-                        rem = (uint32_t)(dx > 0.0f ? gnx - 1 - ix : ix) | (uint32_t)(dy > 0.0f ? gny - 1 - iy : iy) << 8 |
+                        rem = (uint32_t)(dx > 0.0f ? gnx - 1 - ix : ix) | (SHEET ? 0u : (uint32_t)(dy > 0.0f ? gny - 1 - iy : iy) << 8) |
                               (uint32_t)(dz > 0.0f ? gnz - 1 - iz : iz) << 16;
                         const uint32_t hdr = g_cells[ci];
                         k = (int)(hdr >> 12), kend = k + (int)((hdr >> cnt_shift) & 63u);
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 t_res = 0.0f;
                 // |size / d| per axis: what one step adds to the leave distance
                 const float dtx = g_size.x * fabsf(bp.idx), dty = g_size.y * fabsf(bp.idy), dtz = g_size.z * fabsf(bp.idz);
-                const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? gnx : -gnx, sz = dz > 0.0f ? gnx * gny : -(gnx * gny);
+                const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? gnx : -gnx, sz = SHEET ? (dz > 0.0f ? gnx : -gnx) : (dz > 0.0f ? gnx * gny : -(gnx * gny));
                 // cell by cell: the wave first drains the lists of the cells its lanes stand in (one sphere per lane and
                 // pass), then every lane steps (measured: 47.4 ms against 54.8 for one flattened loop in which a lane either
                 // tests or steps, RTIOW 256 spp)
@@ -670,8 +675,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const bool cut = RT_WALK_TAIL > 0 && (int)__popcll(walking) <= RT_WALK_TAIL &&
                                      (int)__popcll(__builtin_amdgcn_ballot_w64(active) & ~walking) >= RT_WALK_WAITING;
                     if (live && !(k < kend)) {
-                        const float tnext = fminf(fminf(tmx, tmy), tmz);
-                        const bool xle = tmx == tnext, yle = !xle && tmy == tnext;
+                        const float tnext = SHEET ? fminf(tmx, tmz) : fminf(fminf(tmx, tmy), tmz);
+                        const bool xle = tmx == tnext, yle = !SHEET && !xle && tmy == tnext;
                         const int sh = xle ? 0 : (yle ? 8 : 16);
                         if (tnext > fminf(t_exit, best_t * 1.0001f) || ((rem >> sh) & 255u) == 0u) {
                             live = false;
@@ -680,7 +685,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                             t_res = tnext;
                         } else {
                             ci += xle ? sx : (yle ? sy : sz);
-                            tmx += xle ? dtx : 0.0f, tmy += yle ? dty : 0.0f, tmz += (xle || yle) ? 0.0f : dtz;
+                            tmx += xle ? dtx : 0.0f, tmz += (xle || yle) ? 0.0f : dtz;
+                            if (!SHEET) tmy += yle ? dty : 0.0f;
                             rem -= 1u << sh;
                             const uint32_t hdr = g_cells[ci];
                             k = (int)(hdr >> 12), kend = k + (int)((hdr >> cnt_shift) & 63u);
@@ -1116,7 +1122,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 }
             }
             // (a lane whose grid walk was cut short has no result yet: its query goes on in the next iteration)
-            const bool unfinished = CULL == 5 && t_res != 0.0f;
+            const bool unfinished = GRID && t_res != 0.0f;
             if (COUNT) {
                 if (!unfinished) c_queries++;
                 const unsigned long long alive = __builtin_amdgcn_ballot_w64(true);
@@ -1598,6 +1604,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 // automatically for scenes too large for LDS)
 #define RT_VARIANT_TABLE(X)        \
     X(0, true, true, false, 5)     \
+    X(2, true, true, false, 6)     \
     X(1, false, true, false, 5)    \
     X(4, true, true, false, 4)     \
     X(8, true, true, true, 1)      \

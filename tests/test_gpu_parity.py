@@ -502,3 +502,30 @@ def test_scenes_without_a_grid_fall_back_to_the_cluster_search(rtmi, rtcheck):
     assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
     with pytest.raises(rtmi.RtmiError, match="grid"):
         sc.render(rtmi.Opts(seed=SEED, variant=1))
+
+
+def test_sheet_walk_equals_the_3d_walk_and_the_flat_scan(rtmi, rtcheck, monkeypatch):
+    """A grid that is one cell high (RTIOW's spheres on the ground) is walked along x and z only (variant 2, what
+    variant 0 picks by itself there).  Same cells, same tests, same bytes as the 3-D walk (RTMI_NO_SHEET=1) and as the
+    linear scan; a volume has no such grid and refuses variant 2."""
+    sc = rtmi.Scene.rtiow(11, 160, 90, 6, 50)
+    flat = sc.render(rtmi.Opts(seed=SEED, variant=16))
+    auto = _assert_same(rtmi, rtcheck, sc, variant=0)
+    sheet = sc.render(rtmi.Opts(seed=SEED, variant=2))
+    assert np.array_equal(auto, flat) and np.array_equal(sheet, flat)
+    # a camera inside the sheet, looking along it: long walks through many cells, rays that leave through the top
+    low = rtmi.Scene.rtiow(11, 160, 90, 4, 50)
+    low.camera((0.3, 0.25, 0.2), (8.0, 0.3, 6.0), (0, 1, 0), 70.0, 160 / 90, 0.05, 4.0)
+    assert np.array_equal(low.render(rtmi.Opts(seed=3, variant=2)), low.render(rtmi.Opts(seed=3, variant=16)))
+    assert np.array_equal(low.render(rtmi.Opts(seed=3, variant=2)), low.render(rtmi.Opts(seed=3, variant=1)))  # (variant 1 walks in 3-D)
+    vol = rtmi.Scene.new(64, 40, 3, 10)
+    vol.set_background((0.5, 0.7, 1.0), sky_gradient=True, defocus_blur=False)
+    vol.camera((0, 0, 12), (0, 0, 0), (0, 1, 0), 40.0, 1.6, 0.0, 12.0)
+    m = vol.lambertian((0.5, 0.5, 0.5))
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        c = rng.uniform(-3, 3, 3)
+        vol.sphere((float(c[0]), float(c[1]), float(c[2])), 0.15, m)
+    with pytest.raises(rtmi.RtmiError):
+        vol.render(rtmi.Opts(seed=1, variant=2))
+    assert np.array_equal(vol.render(rtmi.Opts(seed=1)), vol.render(rtmi.Opts(seed=1, variant=16)))
