@@ -146,6 +146,12 @@ __device__ __forceinline__ float rt_sqrtf(float x) {
 #endif
 }
 
+// number of set bits of a lane mask as a 32-bit SCALAR (popcll's result is compared as a 64-bit value, for which the
+// scalar unit has no ordered compare: the comparison then runs on the vector ALU, once per pass of the walk's loops)
+__device__ __forceinline__ int mask_count(unsigned long long m) {
+    return __builtin_amdgcn_readfirstlane(__builtin_popcount((uint32_t)m) + __builtin_popcount((uint32_t)(m >> 32)));
+}
+
 // checker_texture::value, texture.cuh:44-52: sign of sin(10x)sin(10y)sin(10z) as the
 // parity of floor(10x/pi) + floor(10y/pi) + floor(10z/pi); zero factor -> even
 __device__ __forceinline__ bool checker_odd(float px, float py, float pz) {
@@ -663,7 +669,11 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                             RT_SPHERE_TEST(S, idx)
                         }
 #endif
-                        if (RT_STEP_AT < 65 && (int)__popcll(__builtin_amdgcn_ballot_w64(live && !(k < kend))) >= RT_STEP_AT) break;
+                        // (the masks of the two conditions are combined as scalars, and the count is declared wave-uniform:
+                        //  ballot(a && b) of two lane masks goes through a VGPR, and its popcount is compared as a vector)
+                        if (RT_STEP_AT < 65 &&
+                            mask_count(__builtin_amdgcn_ballot_w64(live) & ~__builtin_amdgcn_ballot_w64(k < kend)) >= RT_STEP_AT)
+                            break;
                     }
                     if (COUNT) c_groups++;
                     // The tail: a wave's walk lasts as long as its slowest lane's (11 test and 4 step passes for 2.8 tests
@@ -672,8 +682,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     // iteration, together with the new queries (the walk is front to back: nothing nearer than the
                     // boundary was found, and whatever was found beyond it is found again in its own cell).
                     const unsigned long long walking = __builtin_amdgcn_ballot_w64(live);
-                    const bool cut = RT_WALK_TAIL > 0 && (int)__popcll(walking) <= RT_WALK_TAIL &&
-                                     (int)__popcll(__builtin_amdgcn_ballot_w64(active) & ~walking) >= RT_WALK_WAITING;
+                    const bool cut = RT_WALK_TAIL > 0 && mask_count(walking) <= RT_WALK_TAIL &&
+                                     mask_count(__builtin_amdgcn_ballot_w64(active) & ~walking) >= RT_WALK_WAITING;
                     if (live && !(k < kend)) {
                         const float tnext = SHEET ? fminf(tmx, tmz) : fminf(fminf(tmx, tmy), tmz);
                         const bool xle = tmx == tnext, yle = !SHEET && !xle && tmy == tnext;
@@ -1325,7 +1335,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         // 19.97 ms: the host sets 12 for launches with many tiles per wave and 63 for small ones.
         bool fetch = exhausted && !queue_empty;
         if (c_valid && idle != 0ull && fetch) {
-            if ((int)__popcll(~idle) <= P.orphan_max) {
+            if (mask_count(~idle) <= P.orphan_max) {
                 if (active && slot == -2) slot = (c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7);
                 flush_tile(c_acc, c_x0, c_band);
                 c_valid = false;
@@ -1376,7 +1386,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const int k = cursor + rank;
-                if (c_valid) cursor = min(cursor + (int)__popcll(idle), c_pool);
+                if (c_valid) cursor = min(cursor + mask_count(idle), c_pool);
                 sp = k & 63;
                 // row and validity of pixel sp live in lane sp's registers (all lanes take part)
                 spy = __shfl(c_hy, sp, 64);
