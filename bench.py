@@ -63,6 +63,7 @@ F_BOX = 12             # slab test of one box: 6 fma (the min/max/compare that f
 F_CULL_SETUP = 17      # per query: 3 reciprocals, margin (mul + add), 6 shifted origins (add + mul each)
 F_GRID_SETUP = 8       # per query: 3 reciprocals, |o|^2 (mul + 2 fma)
 F_GRID_ENTER = 27      # per lane that reaches the grid: entry point 3 fma, cell index 3 x (sub + mul), leave distances 3 x (fma + sub + mul), step lengths 3 mul
+F_GRID_ENTER_SHEET = 18  # the same for a grid one cell high (walk along x and z only): 2 fma, 2 x (sub + mul), 2 x (fma + sub + mul), 2 mul
 F_GRID_STEP = 2        # per cell step: one leave distance += step length, best_t x (1 + 1e-4); min / compare / select = 0
 F_RANGE_LOOKUP = 24    # per window box a ray reaches: 6 fma for the clipped segment's end points, 2 axes x (2 margin + 2 offset + 2 scale)
 
@@ -302,7 +303,9 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
         shading = linear_flops - per_query_linear * c["queries"]  # 46 S + 30 H + scatter + 25 M
         flops_strict = 17 * sphere_tests + n_other * c["queries"] + shading            # box tests = accelerator overhead
         flops = flops_strict + F_BOX * box_tests + setup
-        search = {5: "uniform grid, per-lane 3-D DDA over two-tier cell lists (default kernel)",
+        search = {5: ("uniform grid one cell high, per-lane x-z DDA over two-tier cell lists (default kernel; counted by the 3-D "
+                      "walk's diagnostic kernel: same cells, same tests)") if c.get("grid_sheet") and args.variant in (0, 2)
+                     else "uniform grid, per-lane 3-D DDA over two-tier cell lists (default kernel)",
                   3: "candidate clusters from range tables, per-lane cluster lists", 4: "range tables, work-balanced cluster tests",
                   2: "per-lane cluster lists through the two-level box hierarchy"}.get(c.get("cull_mode"), "clusters")
         roof["mode"] = f"culled hittable_list: {search}" if culled else "linear hittable_list scan (variant 16)"
@@ -368,7 +371,8 @@ def executed_tests(c: dict, lanes: float):
         # test); lanes that reach it compute their entry cell and walk: one sphere test per list entry of every cell
         # visited (lane_clusters counts single spheres here), one step per further cell
         return (q * c["cull_prefix"] + c["lane_clusters"], q,
-                F_GRID_SETUP * q + F_GRID_ENTER * c["lane_groups"] + F_GRID_STEP * c["lane_cands"])
+                F_GRID_SETUP * q + (F_GRID_ENTER_SHEET if c.get("grid_sheet") else F_GRID_ENTER) * c["lane_groups"]
+                + F_GRID_STEP * c["lane_cands"])
     if c.get("cull_mode", 2) == 4:
         # work-balanced ablation: no per-cluster box tests; every candidate cluster's spheres are tested (by some lane)
         return (q * c["cull_prefix"] + c["lane_clusters"] * c["cull_cluster_size"], q * c["cull_windows"],

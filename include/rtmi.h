@@ -289,13 +289,14 @@ typedef struct rt_stats {
     uint64_t lane_cands;  /* culling by range tables: candidate clusters per LANE before the per-cluster box test;
                              grid: cell steps per LANE (lane_groups = lanes that entered the grid, lane_clusters =
                              sphere tests per LANE) */
-    int32_t cull_mode;    /* candidate search of the kernel that ran: 5 uniform grid, 3 range tables, 2 box hierarchy
-                             per lane, 1 wave votes, 0 none (flat scan) */
+    int32_t cull_mode;    /* candidate search of the kernel that ran: 5 uniform grid (6: its walk along x and z only, for a
+                             grid one cell high), 3 range tables, 2 box hierarchy per lane, 1 wave votes, 0 none (flat scan) */
     int32_t cull_windows; /* windows of 64 clusters */
     double gather_ms;     /* root device: end of its own render -> assembled frame (ncclGather + row placement,
                              includes waiting for slower peers) */
     int32_t devices_used;
-    int32_t reserved_;
+    int32_t grid_sheet;   /* rt_render_hip_count: 1 if the scene's grid is one cell high, i.e. the default kernel walks it along
+                             x and z only (variant 2; the counting kernel itself walks in 3-D: same cells, same tests) */
 } rt_stats;
 
 void rt_opts_default(rt_opts *o);

@@ -107,7 +107,7 @@ class Stats(C.Structure):
         ("cull_prefix", C.c_int32),
         ("cull_clusters", C.c_int32), ("cull_groups", C.c_int32), ("cull_cluster_size", C.c_int32),
         ("wave_start_spread_us", C.c_double), ("wave_end_spread_us", C.c_double), ("wave_span_us", C.c_double),
-        ("lane_cands", C.c_uint64), ("cull_mode", C.c_int32), ("cull_windows", C.c_int32), ("gather_ms", C.c_double), ("devices_used", C.c_int32), ("reserved_", C.c_int32),
+        ("lane_cands", C.c_uint64), ("cull_mode", C.c_int32), ("cull_windows", C.c_int32), ("gather_ms", C.c_double), ("devices_used", C.c_int32), ("grid_sheet", C.c_int32),
     ]
 
     def as_dict(self):

@@ -1087,6 +1087,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->cull_prefix = P.np, stats->cull_clusters = P.ncl, stats->cull_groups = P.ngr;
             stats->cull_cluster_size = P.cluster;
             stats->cull_mode = variant_cull_mode(variant), stats->cull_windows = P.nwin;
+            stats->grid_sheet = P.grid_sheet;
         }
     }
     return RT_OK;

@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         out["kernel_stats"].append({k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
-        if "render_kernel<false, true, true, false, 5," in r["Kernel_Name"]:  # the default kernel
+        if "render_kernel<false, true, true, false, 5," in r["Kernel_Name"] or "render_kernel<false, true, true, false, 6," in r["Kernel_Name"]:  # the default kernel (6: its x-z walk for sheets)
             out["render_dispatch"] = {k: r[k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")}
             break
 agg = collections.defaultdict(float); launches = collections.defaultdict(int)
