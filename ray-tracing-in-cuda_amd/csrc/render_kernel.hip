@@ -76,6 +76,9 @@
 #endif
 // candidate predicate of a sphere test: a real root that is not behind the origin.  1: evaluated without short-circuit
 // (three compares, one branch) instead of as two nested branches -- measured 146.5 against 145.5 ms, so 0
+#ifndef RT_KEY_BARRIER
+#define RT_KEY_BARRIER 1
+#endif
 #ifndef RT_CAND_FLAT
 #define RT_CAND_FLAT 0
 #endif
@@ -99,6 +102,13 @@ __device__ __forceinline__ void rng_start(LaneRng &r, uint32_t pixel, uint32_t s
 #if defined(RT_ABLATE) && (RT_ABLATE & 4)
     r.g.x = pixel * 2654435761u, r.g.y = sample * 40503u + 1u, r.g.z = k0 ^ pixel, r.g.w = k1 + sample + 7u;
 #else
+    // The key schedule (k + r W for the ten rounds) is wave-uniform and loop-invariant, so the compiler computes the twenty
+    // words once per launch -- and then, out of scalar registers, keeps them in the lanes of a spill VGPR and fetches
+    // them with v_readlane (plus hazard nops) in every seeding.  Behind this barrier the key is a fresh scalar of the
+    // iteration, and the schedule is two s_add per round.
+#if RT_KEY_BARRIER
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
     r.g = xor128_seed(pixel, sample, k0, k1);
 #endif
 }
