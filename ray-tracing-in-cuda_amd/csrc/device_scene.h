@@ -69,6 +69,8 @@ struct RenderParams {
     uint32_t flags;
     float rr_p;              // Russian-roulette survival probability per bounce, 0 = off
     int32_t width, height, max_depth;
+    float inv_wm1, inv_hm1;  // 1 / (W - 1), 1 / (H - 1) in fp32 (the jitter's scale, main.cu:96-97): computed by the host, because a
+                             // value the kernel derives before its main loop is a VGPR that gets spilled to scratch
     // shard geometry (see rt_opts)
     int32_t tile_rows, tile_first, tile_stride, num_tiles, local_rows;
     // samples

@@ -858,6 +858,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     P.flags = s.flags;
     P.rr_p = s.rr_p;
     P.width = s.width, P.height = s.height, P.max_depth = s.max_depth;
+    P.inv_wm1 = 1.0f / (float)(s.width - 1), P.inv_hm1 = 1.0f / (float)(s.height - 1);  // IEEE fp32 divisions, as the checker's
     P.tile_rows = sh.tile_rows, P.tile_first = sh.tile_first, P.tile_stride = sh.tile_stride;
     P.num_tiles = sh.num_tiles, P.local_rows = sh.local_rows;
     P.sample_first = sample_first, P.sample_count = sample_count;

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     const int ns = P.ns, nr = P.nr, nc = P.nc, nt = P.nt;
     const float4 *tri = hot + P.off_tri_hot;
     // u = (x + xi) / (W - 1), main.cu:96-97, evaluated as a multiply by the fp32 reciprocal (as the checker does)
-    const float inv_wm1 = 1.0f / (float)(P.width - 1), inv_hm1 = 1.0f / (float)(P.height - 1);
+    // (the two reciprocals come with the launch parameters: computed here they were vector registers, spilled to scratch and
+    //  fetched back with two dependent scratch loads in every refill)
 
     uint32_t c_samples = 0, c_queries = 0, c_hits = 0, c_misses = 0;
     uint32_t c_scatter0 = 0, c_scatter1 = 0, c_scatter2 = 0, c_scatter3 = 0;
@@ -1413,8 +1414,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 cur_p = sp;
                 slot = -2;
                 rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss, k0, k1);
-                u = ((float)spx + rng_next<COUNT>(rng)) * inv_wm1;
-                v = ((float)spy + rng_next<COUNT>(rng)) * inv_hm1;
+                u = ((float)spx + rng_next<COUNT>(rng)) * P.inv_wm1;
+                v = ((float)spy + rng_next<COUNT>(rng)) * P.inv_hm1;
                 if (COUNT) c_samples++;
             }
             started = start;
