@@ -256,7 +256,9 @@ typedef struct rt_opts {
                              votes, bit 6 per-lane cluster lists through the two-level box hierarchy (round 1's
                              default), bit 7 per-lane cluster lists through the range tables (what scenes without a
                              grid fall back to); 40 / 104 / 136 = variant 0 / 64 / 128 with all tables in global
-                             memory (what they switch to for scenes too large for LDS) */
+                             memory (what they switch to for scenes too large for LDS); 2 = variant 0 for a grid one
+                             cell high (walk along x and z only) and 44 = variant 40 over the wide grid tables of scenes
+                             with 65536 sphere slots or more: both picked by variant 0 itself */
 } rt_opts;
 
 typedef struct rt_stats {

@@ -98,6 +98,8 @@ struct RenderParams {
     // count), items (16-bit sphere slots); grid_cells == 0: the scene has no grid (no clustered spheres, or a cell with
     // more than 255 spheres)
     int32_t off_grid, off_grid_cells, off_grid_items, grid_cells;
+    int32_t grid_wide;       // 1: wide grid tables (65536 sphere slots or more): 32-bit list entries, two 32-bit words per cell {first
+                             // entry, (n_near << 8) | n_all}, up to 1023 cells per axis and 255 entries per cell (CULL == 7, global memory)
     int32_t grid_sheet;      // 1: the grid is one cell high (ny == 1): the walk steps along x and z only (CULL == 6)
     int32_t hot_vec4_grid;   // float4 count of the hot part through the grid tables (what the grid-walk kernel stages)
     int32_t hot_vec4_tables; // float4 count of the hot part including the range tables (what the range-table kernel stages)

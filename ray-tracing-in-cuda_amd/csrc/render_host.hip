@@ -233,15 +233,23 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     // it at all, scan every clustered sphere: rare, and the flat scan is the definition of the result.
     // (0.004 cell + 1e-5 (max|c| + 1)) more covers the walk's own rounding: the entry point, the cell boundaries, up to
     // 255 accumulated leave distances.)
-    std::vector<uint32_t> grid_cells;   // (first item << 12) | (n_near << 6) | n_all
-    std::vector<uint16_t> grid_items;   // sphere slots; a cell's near-tier entries first
+    std::vector<uint32_t> grid_cells;   // (first item << 12) | (n_near << 6) | n_all;  wide: {first item, (n_near << 8) | n_all} per cell
+    std::vector<uint32_t> grid_items;   // sphere slots; a cell's near-tier entries first (stored as 16-bit words unless wide)
+    bool grid_wide = false;
     float grid_min[3] = {0, 0, 0}, grid_size[3] = {1, 1, 1};
     int grid_n[3] = {0, 0, 0};
     float grid_ob2[2] = {0.0f, 0.0f}, grid_shrink = 0.0f;
     {
         static const double cell_factor = getenv("RTMI_GRID_CELL") ? atof(getenv("RTMI_GRID_CELL")) : 1.0;
         static const double ob_env = getenv("RTMI_GRID_OB") ? atof(getenv("RTMI_GRID_OB")) : 0.0;  // experiments
-        bool ok = !rest.empty() && ns_slots < 65536;
+        // 65536 sphere slots or more: the WIDE table format (32-bit list entries, 64-bit cell words, up to 1023 cells per
+        // axis and 255 entries per cell), read from global memory by its own kernel instance (CULL == 7, variant 44)
+        grid_wide = ns_slots >= 65536;
+        bool ok = !rest.empty();
+        const double max_dim = grid_wide ? 1023.0 : 255.0;
+        const long long max_cells = grid_wide ? (1LL << 21) : (1LL << 18);
+        const size_t max_per_cell = grid_wide ? 255 : 63;
+        const size_t max_items = grid_wide ? ((size_t)1 << 30) : ((size_t)1 << 20);
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, cmax = 0.0, cmax2 = 0.0;
         for (int i : rest) {
             double c2 = 0.0;
@@ -288,18 +296,18 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
                 long long total = 1;
                 for (int a = 0; a < 3; ++a) {
                     const double span = ext[a] + 2.0 * rmax_far;
-                    grid_n[a] = spread[a] ? (int)std::min(255.0, std::max(1.0, std::ceil(span / cell))) : 1;
+                    grid_n[a] = spread[a] ? (int)std::min(max_dim, std::max(1.0, std::ceil(span / cell))) : 1;
                     grid_min[a] = (float)(lo[a] - rmax_far);
                     grid_size[a] = (float)(span / grid_n[a]);
                     total *= grid_n[a];
                 }
-                if (total <= (1 << 18)) break;
+                if (total <= max_cells) break;
                 cell *= 1.3;
             }
             // near-tier lanes clip their rays to the bounds of the near-tier boxes: the far tier's, this much further in
             grid_shrink = (float)((rmax_far - rmax_near) * (1.0 - 1e-6));
             const int nx = grid_n[0], ny = grid_n[1], nz = grid_n[2];
-            std::vector<std::vector<uint16_t>> lists((size_t)nx * ny * nz), extra((size_t)nx * ny * nz);
+            std::vector<std::vector<uint32_t>> lists((size_t)nx * ny * nz), extra((size_t)nx * ny * nz);
             for (size_t k = 0; k < rest.size(); ++k) {
                 // the slot of this sphere: clusters of csize behind the prefix, one padding slot per cluster
                 const int slot = np_slots + (int)(k / csize) * cstride + (int)(k % csize);
@@ -317,28 +325,32 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
                     for (int iy = c0[1]; iy <= c1[1]; ++iy)
                         for (int ix = c0[0]; ix <= c1[0]; ++ix) {
                             const bool near = ix >= n0[0] && ix <= n1[0] && iy >= n0[1] && iy <= n1[1] && iz >= n0[2] && iz <= n1[2];
-                            (near ? lists : extra)[((size_t)iz * ny + iy) * nx + ix].push_back((uint16_t)slot);
+                            (near ? lists : extra)[((size_t)iz * ny + iy) * nx + ix].push_back((uint32_t)slot);
                         }
             }
-            grid_cells.resize(lists.size());
+            grid_cells.resize(lists.size() * (grid_wide ? 2 : 1));
             for (size_t c = 0; c < lists.size() && ok; ++c) {
                 const size_t n_near = lists[c].size(), n_all = n_near + extra[c].size();
-                if (n_all > 63 || grid_items.size() + n_all >= (1u << 20)) ok = false;  // a clump: keep the cluster search
-                grid_cells[c] = ((uint32_t)grid_items.size() << 12) | ((uint32_t)n_near << 6) | (uint32_t)n_all;
+                if (n_all > max_per_cell || grid_items.size() + n_all >= max_items) ok = false;  // a clump: keep the cluster search
+                if (grid_wide)
+                    grid_cells[2 * c] = (uint32_t)grid_items.size(), grid_cells[2 * c + 1] = ((uint32_t)n_near << 8) | (uint32_t)n_all;
+                else
+                    grid_cells[c] = ((uint32_t)grid_items.size() << 12) | ((uint32_t)n_near << 6) | (uint32_t)n_all;
                 grid_items.insert(grid_items.end(), lists[c].begin(), lists[c].end());
                 grid_items.insert(grid_items.end(), extra[c].begin(), extra[c].end());
             }
         }
         if (!ok) grid_cells.clear(), grid_items.clear(), grid_n[0] = grid_n[1] = grid_n[2] = 0;
     }
-    L.grid_cells = (int)grid_cells.size();
-    L.grid_sheet = (!grid_cells.empty() && grid_n[1] == 1) ? 1 : 0;
+    L.grid_cells = (int)(grid_cells.size() / (grid_wide ? 2 : 1));
+    L.grid_wide = (!grid_cells.empty() && grid_wide) ? 1 : 0;
+    L.grid_sheet = (!grid_cells.empty() && grid_n[1] == 1 && !grid_wide) ? 1 : 0;
     L.off_grid = off;  // 4 records {min.xyz, ob_near^2} {1/size.xyz, ob_far^2} {size.xyz, shrink} {nx, ny, nz, -}, then cells, then items
     off += 4;
     L.off_grid_cells = off;
     off += ((int)grid_cells.size() + 3) / 4;
     L.off_grid_items = off;
-    off += ((int)grid_items.size() + 7) / 8;
+    off += grid_wide ? ((int)grid_items.size() + 1 + 3) / 4 : ((int)grid_items.size() + 1 + 7) / 8;  // (+ 1: the pair test reads one entry past a list)
     L.hot_vec4_grid = off;  // what the grid-walk kernel stages into LDS
     L.rt_axes = axes;
     L.rt_stride = 2 + n_axes * (RT_SLABS * RT_SLABS / 2);  // float4 records per window: {min, 1/width} + masks (2 per record)
@@ -522,7 +534,14 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         }
         g[3] = grid_ob2[0], g[7] = grid_ob2[1], g[11] = grid_shrink;
         if (!grid_cells.empty()) memcpy(rec4(L.off_grid_cells), grid_cells.data(), grid_cells.size() * sizeof(uint32_t));
-        if (!grid_items.empty()) memcpy(rec4(L.off_grid_items), grid_items.data(), grid_items.size() * sizeof(uint16_t));
+        if (!grid_items.empty()) {
+            if (grid_wide) {
+                memcpy(rec4(L.off_grid_items), grid_items.data(), grid_items.size() * sizeof(uint32_t));
+            } else {
+                uint16_t *dst = reinterpret_cast<uint16_t *>(rec4(L.off_grid_items));
+                for (size_t i = 0; i < grid_items.size(); ++i) dst[i] = (uint16_t)grid_items[i];
+            }
+        }
     }
     for (int k = 0; k < L.nr; ++k) {
         const rt_prim &p = s.prims[rec[k]];
@@ -878,7 +897,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // (each candidate search stages the part of the hot tables it reads)
     auto hot_bytes_of = [&](unsigned v) {
         const int mode = variant_cull_mode(v);
-        return (size_t)((mode == 5 || mode == 6) ? P.hot_vec4_grid : ((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4)) * 16;
+        return (size_t)((mode == 5 || mode == 6 || mode == 7) ? P.hot_vec4_grid : ((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4)) * 16;
     };
     static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
                                                                              : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;
@@ -890,6 +909,18 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // (variant 2 is variant 0 for a grid that is one cell high: a walk along x and z only; the counting kernel and the
     //  builds with triangles / image textures only exist for the 3-D walk, whose cells and tests are the same)
     static const bool no_sheet = getenv("RTMI_NO_SHEET") != nullptr;  // A/B knob
+    // (variant 44 is the grid walk over the WIDE tables of scenes with 65536 sphere slots or more: global memory only;
+    //  the counting kernel and the triangle / texture builds have no wide form: they take the cluster search there)
+    const bool wide_unusable = P.grid_wide && (count || ext);
+    if (wide_unusable) P.grid_cells = 0, P.grid_wide = 0;
+    if (P.grid_wide && (variant == 1 || variant == 2 || variant == 40)) {
+        set_error("kernel variant %u reads the 16-bit grid tables; this scene (65536 sphere slots or more) has the wide ones: use variant 0 or 44", variant);
+        return RT_ERR_LIMIT;
+    }
+    if (variant == 44 && !P.grid_wide) {
+        set_error("kernel variant 44 walks the wide grid tables of scenes with 65536 sphere slots or more, which this scene does not have");
+        return RT_ERR_LIMIT;
+    }
     if (variant == 2 && (count || ext)) variant = 0;
     if (variant == 2 && !P.grid_sheet) {
         set_error("kernel variant 2 walks a grid that is one cell high, which this scene does not have");
@@ -897,7 +928,8 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     }
     if (variant == 0) {
         if (P.grid_cells > 0 || P.ncl == 0) {
-            if (hot_bytes_of(0) > global_threshold) variant = 40;
+            if (P.grid_wide) variant = 44;
+            else if (hot_bytes_of(0) > global_threshold) variant = 40;
             else if (P.grid_sheet && !count && !ext && !no_sheet) variant = 2;
         } else {
             const int n_axes = (P.rt_axes & 1) + ((P.rt_axes >> 1) & 1) + ((P.rt_axes >> 2) & 1);
@@ -907,7 +939,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     }
     if (variant == 64 && hot_bytes_of(64) > global_threshold) variant = 104;
     size_t hot_bytes = hot_bytes_of(variant);
-    if ((variant_cull_mode(variant) == 5 || variant_cull_mode(variant) == 6) && P.grid_cells == 0 && P.ncl > 0) {
+    if ((variant_cull_mode(variant) == 5 || variant_cull_mode(variant) == 6 || variant_cull_mode(variant) == 7) && P.grid_cells == 0 && P.ncl > 0) {
         set_error("kernel variant %u walks the uniform grid, which this scene does not have (more than 65535 sphere slots, "
                   "or more than 63 spheres in one cell)", variant);
         return RT_ERR_LIMIT;

@@ -251,7 +251,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     extern __shared__ float4 lds[];
     // stage the hot tables (hittable_list contents) into LDS
     // CULL == 6 is CULL == 5 for a grid that is one cell high (a sheet of spheres on the ground: RTIOW): the walk has no y axis
-    constexpr bool GRID = CULL == 5 || CULL == 6, SHEET = CULL == 6;
+    // CULL == 7 is CULL == 5 over the WIDE grid tables of scenes with 65536 sphere slots or more (32-bit list entries, two
+    // words per cell, 10 bits of steps per axis): global memory only (SCALAR)
+    constexpr bool GRID = CULL == 5 || CULL == 6 || CULL == 7, SHEET = CULL == 6, WIDE = CULL == 7;
+    static_assert(!WIDE || SCALAR, "the wide grid tables are read from global memory");
     const int staged = SCALAR ? 0 : (GRID ? P.hot_vec4_grid : ((CULL == 3 || CULL == 4) ? P.hot_vec4_tables : P.hot_vec4));
     for (int i = threadIdx.x; i < staged; i += 256) lds[i] = image[i];
     // per-wave tile accumulator of the current work item: 64 pixels x rgb, 64-bit fixed point
@@ -586,7 +589,19 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 // which tier of the cells' lists covers this lane's origin (the packer: |o| against ob_near, ob_far)
                 const float o2 = fmaf(ox, ox, fmaf(oy, oy, oz * oz));
                 const bool tier_far = o2 > g_min.w, beyond = o2 > g_inv.w;
-                const int cnt_shift = tier_far ? 0 : 6;  // header: (first << 12) | (n_near << 6) | n_all
+                const int cnt_shift = tier_far ? 0 : (WIDE ? 8 : 6);  // header: (first << 12) | (n_near << 6) | n_all; wide: {first, (n_near << 8) | n_all}
+                constexpr int REM_BITS = WIDE ? 10 : 8;            // steps left per axis, packed in one register
+                constexpr uint32_t REM_MASK = (1u << REM_BITS) - 1u, CNT_MASK = WIDE ? 255u : 63u;
+                const uint32_t *g_items32 = reinterpret_cast<const uint32_t *>(g_items);
+                auto cell_list = [&](int cell, int &first, int &end) {  // a cell's list entries [first, end) of this lane's tier
+                    if (WIDE) {
+                        const uint2 h = reinterpret_cast<const uint2 *>(g_cells)[cell];
+                        first = (int)h.x, end = first + (int)((h.y >> cnt_shift) & CNT_MASK);
+                    } else {
+                        const uint32_t h = g_cells[cell];
+                        first = (int)(h >> 12), end = first + (int)((h >> cnt_shift) & CNT_MASK);
+                    }
+                };
                 bool far_scan = false;
                 // the grid's bounds (un-grown: the lists carry the growth); the near tier's lie g_size.w further in
                 const float shrink = tier_far ? 0.0f : g_size.w;
@@ -629,10 +644,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         tmx = dx == 0.0f ? INFINITY : (fmaf((float)(ix + (dx > 0.0f ? 1 : 0)), g_size.x, g_min.x) - ox) * bp.idx;
                         if (!SHEET) tmy = dy == 0.0f ? INFINITY : (fmaf((float)(iy + (dy > 0.0f ? 1 : 0)), g_size.y, g_min.y) - oy) * bp.idy;
                         tmz = dz == 0.0f ? INFINITY : (fmaf((float)(iz + (dz > 0.0f ? 1 : 0)), g_size.z, g_min.z) - oz) * bp.idz;
-                        rem = (uint32_t)(dx > 0.0f ? gnx - 1 - ix : ix) | (SHEET ? 0u : (uint32_t)(dy > 0.0f ? gny - 1 - iy : iy) << 8) |
-                              (uint32_t)(dz > 0.0f ? gnz - 1 - iz : iz) << 16;
-                        const uint32_t hdr = g_cells[ci];
-                        k = (int)(hdr >> 12), kend = k + (int)((hdr >> cnt_shift) & 63u);
+                        rem = (uint32_t)(dx > 0.0f ? gnx - 1 - ix : ix) | (SHEET ? 0u : (uint32_t)(dy > 0.0f ? gny - 1 - iy : iy) << REM_BITS) |
+                              (uint32_t)(dz > 0.0f ? gnz - 1 - iz : iz) << (2 * REM_BITS);
+                        cell_list(ci, k, kend);
                         if (COUNT && t_res == 0.0f) c_lane_groups++, c_group_maxpop += tier_far ? 1u : 0u;
                     }
                 }
@@ -660,8 +674,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         // bookkeeping and a taken branch) instead of n.  A list of odd length reads the never-hit slot
                         // behind the first cluster for its second half.
                         if (k < kend) {
-                            const int idx = (int)g_items[k];
-                            const int j_raw = (int)g_items[k + 1];  // (one entry past the list at worst: the next list, or whatever follows the lists in LDS / in the scene image)
+                            const int idx = WIDE ? (int)g_items32[k] : (int)g_items[k];
+                            const int j_raw = WIDE ? (int)g_items32[k + 1] : (int)g_items[k + 1];  // (one entry past the list at worst: the next list, or the padding entry behind the last one)
                             const int jdx = k + 1 < kend ? j_raw : P.np + CSIZE;
                             if (COUNT) c_lane_clusters += k + 1 < kend ? 2u : 1u;
                             k += 2;
@@ -674,7 +688,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         }
 #else
                         if (k < kend) {
-                            const int idx = (int)g_items[k++];
+                            const int idx = WIDE ? (int)g_items32[k] : (int)g_items[k];
+                            ++k;
                             const float4 S = sph[idx];
                             if (COUNT) c_lane_clusters++;
                             RT_SPHERE_TEST(S, idx)
@@ -698,8 +713,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     if (live && !(k < kend)) {
                         const float tnext = SHEET ? fminf(tmx, tmz) : fminf(fminf(tmx, tmy), tmz);
                         const bool xle = tmx == tnext, yle = !SHEET && !xle && tmy == tnext;
-                        const int sh = xle ? 0 : (yle ? 8 : 16);
-                        if (tnext > fminf(t_exit, best_t * 1.0001f) || ((rem >> sh) & 255u) == 0u) {
+                        const int sh = xle ? 0 : (yle ? REM_BITS : 2 * REM_BITS);
+                        if (tnext > fminf(t_exit, best_t * 1.0001f) || ((rem >> sh) & REM_MASK) == 0u) {
                             live = false;
                         } else if (cut && tnext > t_from) {
                             live = false;
@@ -709,8 +724,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                             tmx += xle ? dtx : 0.0f, tmz += (xle || yle) ? 0.0f : dtz;
                             if (!SHEET) tmy += yle ? dty : 0.0f;
                             rem -= 1u << sh;
-                            const uint32_t hdr = g_cells[ci];
-                            k = (int)(hdr >> 12), kend = k + (int)((hdr >> cnt_shift) & 63u);
+                            cell_list(ci, k, kend);
                             if (COUNT) c_lane_cands++;
                         }
                     }
@@ -1635,6 +1649,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
     X(24, true, true, true, 0)     \
     X(32, true, true, false, 1)    \
     X(40, true, true, true, 5)     \
+    X(44, true, true, true, 7)     \
     X(64, true, true, false, 2)    \
     X(104, true, true, true, 2)    \
     X(128, true, true, false, 3)   \

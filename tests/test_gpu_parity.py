@@ -529,3 +529,39 @@ def test_sheet_walk_equals_the_3d_walk_and_the_flat_scan(rtmi, rtcheck, monkeypa
     with pytest.raises(rtmi.RtmiError):
         vol.render(rtmi.Opts(seed=1, variant=2))
     assert np.array_equal(vol.render(rtmi.Opts(seed=1)), vol.render(rtmi.Opts(seed=1, variant=16)))
+
+
+def test_wide_grid_tables_for_65536_spheres_and_more(rtmi):
+    """Scenes with 65536 sphere slots or more get the WIDE grid tables (32-bit list entries, two words per cell, up to 1023
+    cells per axis) and their own kernel instance (variant 44, global memory); before, such scenes fell back to the box
+    hierarchy.  A volume and a sheet (more than 255 cells along two axes) against the linear scan and the cluster search."""
+    rng = np.random.default_rng(17)
+    vol = rtmi.Scene.new(48, 32, 2, 6)
+    vol.set_background((0.5, 0.7, 1.0), sky_gradient=True, defocus_blur=False)
+    vol.camera((0, 0, 30), (0, 0, 0), (0, 1, 0), 35.0, 1.5, 0.0, 30.0)
+    mats = [vol.lambertian((0.6, 0.5, 0.4)), vol.metal((0.8, 0.8, 0.9), 0.1), vol.dielectric(1.5)]
+    c = rng.uniform(-8, 8, (70000, 3)).astype(np.float32)
+    for i in range(len(c)):
+        vol.sphere((float(c[i, 0]), float(c[i, 1]), float(c[i, 2])), 0.06, mats[i % 3])
+    auto = vol.render(rtmi.Opts(seed=5))  # variant 0 picks 44 here: 1, 2 and 40 (the 16-bit tables) are refused below
+    assert np.array_equal(auto, vol.render(rtmi.Opts(seed=5, variant=44)))
+    assert np.array_equal(auto, vol.render(rtmi.Opts(seed=5, variant=24)))   # the linear scan (tables in global memory)
+    assert np.array_equal(auto, vol.render(rtmi.Opts(seed=5, variant=104)))  # box hierarchy, global tables
+    for bad in (1, 2, 40):
+        with pytest.raises(rtmi.RtmiError):
+            vol.render(rtmi.Opts(seed=5, variant=bad))
+    sheet = rtmi.Scene.new(48, 32, 2, 6)
+    sheet.set_background((0.5, 0.7, 1.0), sky_gradient=True, defocus_blur=False)
+    sheet.camera((3, 2.5, 9), (0, 0, 0), (0, 1, 0), 40.0, 1.5, 0.0, 9.0)
+    m = [sheet.lambertian((0.3, 0.6, 0.3)), sheet.metal((0.9, 0.9, 0.9), 0.0)]
+    sheet.sphere((0, -1000, 0), 1000.0, sheet.lambertian((0.5, 0.5, 0.5)))
+    n = 260  # 260 x 260 = 67600 spheres on a lattice, jittered
+    j = rng.uniform(-0.01, 0.01, (n, n, 2))
+    for a in range(n):
+        for b in range(n):
+            sheet.sphere((float(0.1 * (a - n / 2) + j[a, b, 0]), 0.03, float(0.1 * (b - n / 2) + j[a, b, 1])), 0.03, m[(a + b) % 2])
+    img = sheet.render(rtmi.Opts(seed=9))
+    assert np.array_equal(img, sheet.render(rtmi.Opts(seed=9, variant=44)))
+    assert np.array_equal(img, sheet.render(rtmi.Opts(seed=9, variant=24)))
+    with pytest.raises(rtmi.RtmiError):  # and a small scene has no wide tables
+        rtmi.Scene.rtiow(3, 32, 18, 1, 5).render(rtmi.Opts(seed=1, variant=44))
