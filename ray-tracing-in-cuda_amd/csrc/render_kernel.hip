@@ -76,6 +76,9 @@
 #endif
 // candidate predicate of a sphere test: a real root that is not behind the origin.  1: evaluated without short-circuit
 // (three compares, one branch) instead of as two nested branches -- measured 146.5 against 145.5 ms, so 0
+#ifndef RT_UNDEF_INIT
+#define RT_UNDEF_INIT 1
+#endif
 #ifndef RT_KEY_BARRIER
 #define RT_KEY_BARRIER 1
 #endif
@@ -387,6 +390,11 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         // the winner's hit record, kept for the scatter step
         float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, inv_len = 0;
         int mat = 0, kind = -1;  // kind >= 0: a scatter step is due in (6)
+#if RT_UNDEF_INIT
+        // (only lanes with kind >= 0 read the record, and they have written it; an "undefined" value from an empty asm
+        //  spares the eight v_mov ..., 0 per iteration that the zero initialisers above cost)
+        asm volatile("" : "=v"(px), "=v"(py), "=v"(pz), "=v"(nx), "=v"(ny), "=v"(nz), "=v"(inv_len), "=v"(mat));
+#endif
         bool front = false;
         float tex_r = 0, tex_g = 0, tex_b = 0;  // the texel of an image texture at the hit's (u, v)
         if (__any(active)) {
@@ -616,6 +624,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 int ci = 0, k = 0, kend = 0;
                 uint32_t rem = 0;  // steps left before the ray leaves the grid: x | y << 8 | z << 16
                 float tmx = INFINITY, tmy = INFINITY, tmz = INFINITY, t_exit = 0.0f;
+#if RT_UNDEF_INIT
+                asm volatile("" : "=v"(ci), "=v"(rem), "=v"(tmx), "=v"(tmy), "=v"(tmz), "=v"(t_exit));  // (read by live lanes only, which set them)
+#endif
                 if (P.grid_cells == 0) {
                     // no clustered spheres, no grid (the host refuses this kernel if there are clustered spheres without one)
                 } else if (beyond) {
@@ -1343,6 +1354,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         // ---- (4) refill: lanes without a live path take new samples
         // (render()'s sample loop, main.cu:95-101; camera::get_ray camera.h:32-39)
         float u = 0, v = 0;    // jitter of the sample a lane starts (main.cu:96-97)
+#if RT_UNDEF_INIT
+        asm volatile("" : "=v"(u), "=v"(v));  // (read by the lanes that start a path)
+#endif
         bool started = false;  // this lane starts a new path in this iteration
         const bool need = !active;
         const unsigned long long idle = __ballot(need);
@@ -1456,6 +1470,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         const bool need_s = kind >= 0 && kind <= MK_METAL;
         const bool need_d = started && (P.flags & RT_FLAG_DEFOCUS_BLUR) != 0u;
         float sx = 0, sy = 0, sz = 0, sl2 = 1;
+#if RT_UNDEF_INIT
+        asm volatile("" : "=v"(sx), "=v"(sy), "=v"(sz), "=v"(sl2));  // (read by the lanes that ran the loop below)
+#endif
         if (need_s || need_d) {
             do {
                 sx = rng_pm1<COUNT>(rng);
