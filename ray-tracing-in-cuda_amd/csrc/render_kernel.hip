@@ -76,6 +76,9 @@
 #endif
 // candidate predicate of a sphere test: a real root that is not behind the origin.  1: evaluated without short-circuit
 // (three compares, one branch) instead of as two nested branches -- measured 146.5 against 145.5 ms, so 0
+// per-iteration scratch variables start undefined (an empty asm) instead of zero: 1 = the hit record (37 fewer v_mov: 136.1 ->
+// 134.8 ms, HBM writes 1.15 -> 1.32 GB through three more spilled registers at the item switch), 2 = also the walk's, the
+// rejection loop's and the jitter's (134.6 ms, 1.65 GB: not worth it)
 #ifndef RT_UNDEF_INIT
 #define RT_UNDEF_INIT 1
 #endif
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 int ci = 0, k = 0, kend = 0;
                 uint32_t rem = 0;  // steps left before the ray leaves the grid: x | y << 8 | z << 16
                 float tmx = INFINITY, tmy = INFINITY, tmz = INFINITY, t_exit = 0.0f;
-#if RT_UNDEF_INIT
+#if RT_UNDEF_INIT > 1
                 asm volatile("" : "=v"(ci), "=v"(rem), "=v"(tmx), "=v"(tmy), "=v"(tmz), "=v"(t_exit));  // (read by live lanes only, which set them)
 #endif
                 if (P.grid_cells == 0) {
@@ -1354,7 +1357,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         // ---- (4) refill: lanes without a live path take new samples
         // (render()'s sample loop, main.cu:95-101; camera::get_ray camera.h:32-39)
         float u = 0, v = 0;    // jitter of the sample a lane starts (main.cu:96-97)
-#if RT_UNDEF_INIT
+#if RT_UNDEF_INIT > 1
         asm volatile("" : "=v"(u), "=v"(v));  // (read by the lanes that start a path)
 #endif
         bool started = false;  // this lane starts a new path in this iteration
@@ -1470,7 +1473,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         const bool need_s = kind >= 0 && kind <= MK_METAL;
         const bool need_d = started && (P.flags & RT_FLAG_DEFOCUS_BLUR) != 0u;
         float sx = 0, sy = 0, sz = 0, sl2 = 1;
-#if RT_UNDEF_INIT
+#if RT_UNDEF_INIT > 1
         asm volatile("" : "=v"(sx), "=v"(sy), "=v"(sz), "=v"(sl2));  // (read by the lanes that ran the loop below)
 #endif
         if (need_s || need_d) {
