@@ -41,6 +41,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_scene.h"
 #include "philox.h"
@@ -249,7 +250,11 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 // EXT:      the Taichi renderer's extras -- triangles (taichi-version/hittable.py:38-71) and image textures read at the
 //           hit record's (u, v) (material.py:137-144).  Only the builds for scenes that use them carry the code: it
 //           costs the kernel its register budget (86 spilled VGPRs instead of 23) whether a scene uses it or not.
-template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL, int CSIZE, bool EXT = false>
+// SPH:      the scene holds spheres only (RTIOW, the 3-sphere scene, sample_scene.json): no rectangle / cylinder / triangle
+//           loops, no dispatch on the winner's type -- and, what pays, a dozen fewer launch values and loop-invariant masks
+//           competing for scalar registers (the surplus of those lives in the lanes of a spill VGPR: one v_readlane per use).
+//           Built for the default kernel (variants 0 and 2); chosen by launch_render.
+template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL, int CSIZE, bool EXT = false, bool SPH = false>
 __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SIMD)) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
                                                      unsigned int *__restrict__ queue,
@@ -280,8 +285,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     const float4 *sph = hot;
     const float4 *rect = hot + P.off_rect_hot;
     const float4 *cyl = hot + P.off_cyl_hot;
-    const int ns = P.ns, nr = P.nr, nc = P.nc, nt = P.nt;
+    const int ns = P.ns, nr = SPH ? 0 : P.nr, nc = SPH ? 0 : P.nc, nt = SPH ? 0 : P.nt;
     const float4 *tri = hot + P.off_tri_hot;
+    // original list index of a grouped primitive id (the tie rule)
+    auto lidx = [&](int id) { return SPH ? __float_as_int(image[P.off_sph_cold + id].z) : list_index_of(P, image, id); };
     // u = (x + xi) / (W - 1), main.cu:96-97, evaluated as a multiply by the fp32 reciprocal (as the checker does)
     // (the two reciprocals come with the launch parameters: computed here they were vector registers, spilled to scratch and
     //  fetched back with two dependent scratch loads in every refill)
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 if (!(root < kTMin || best_t < root)) {
                     bool take = true;
                     if (root == best_t && best_id >= 0)
-                        take = list_index_of(P, image, idx) > list_index_of(P, image, best_id);
+                        take = lidx(idx) > lidx(best_id);
                     if (take) {
                         best_t = root;
                         best_id = idx;
@@ -1188,7 +1195,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             if (unfinished) {
             } else if (best_id >= 0) {
                 // hit record of the winner only (the reference fills one per candidate)
-                if (best_id < ns) {
+                if (SPH || best_id < ns) {
                     const float4 s = sph[best_id];
                     const float4 cold = image[P.off_sph_cold + best_id];
                     px = fmaf(best_t, dx, ox), py = fmaf(best_t, dy, oy), pz = fmaf(best_t, dz, oz);
@@ -1718,6 +1725,18 @@ void launch_render(const RenderParams &P, const void *image, unsigned long long 
 #undef RT_LAUNCH_EXT
         return;
     }
+    // sphere-only scenes: the default kernel's builds without the other primitives (RTMI_NO_SPH=1 keeps the general build: A/B knob)
+    static const bool no_sph = getenv("RTMI_NO_SPH") != nullptr;
+    if (!no_sph && (variant == 0 || variant == 2) && P.nr + P.nc + P.nt == 0) {
+        if (variant == 0) {
+            RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, true, true, false, 5, 8, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, none),
+                          hipLaunchKernelGGL((render_kernel<false, true, true, false, 5, 16, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, none))
+        } else {
+            RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, true, true, false, 6, 8, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, none),
+                          hipLaunchKernelGGL((render_kernel<false, true, true, false, 6, 16, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, none))
+        }
+        return;
+    }
 #define RT_LAUNCH(V, POOL, PRE, SCALAR, CULL)                                                                                              \
     case V:                                                                                                                                 \
         RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 8>), g, t, lds_bytes, stream, P, img, acc, queue, none),  \
@@ -1813,6 +1832,10 @@ void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStr
 int set_max_dynamic_lds(size_t bytes) {
 #define RT_ATTR1(K)                                                                                                  \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
+    RT_ATTR1((render_kernel<false, true, true, false, 5, 8, false, true>))
+    RT_ATTR1((render_kernel<false, true, true, false, 5, 16, false, true>))
+    RT_ATTR1((render_kernel<false, true, true, false, 6, 8, false, true>))
+    RT_ATTR1((render_kernel<false, true, true, false, 6, 16, false, true>))
     RT_ATTR1((render_kernel<true, true, true, false, 5, 8>))
     RT_ATTR1((render_kernel<true, true, true, false, 5, 16>))
     RT_ATTR1((render_kernel<true, true, true, true, 5, 8>))
