@@ -83,6 +83,9 @@
 #ifndef RT_UNDEF_INIT
 #define RT_UNDEF_INIT 1
 #endif
+#ifndef RT_ITEM_SCALARS
+#define RT_ITEM_SCALARS 1
+#endif
 #ifndef RT_KEY_BARRIER
 #define RT_KEY_BARRIER 1
 #endif
@@ -326,6 +329,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     int c_x0 = 0, c_band = 0, c_sbegin = 0, c_pool = 0, cursor = 0;  // c_pool = 64 x samples of the item
     bool c_valid = false, queue_empty = false;
     int c_hy = 0, c_hvalid = 0;  // this lane's home pixel in the current item (row, on-image)
+    unsigned long long c_hvmask = 0ull;  // ... and the on-image bits of all 64 home pixels (wave-uniform)
     int mine = 0;                // !POOL: samples of the home pixel started so far (current item)
     // where this lane's live path adds its sample: -2 the current item's accumulator; >= 0 the path
     // outlived its item (an orphan): dense local pixel index for a direct global add
@@ -1422,11 +1426,20 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const int s_end = sample_first + sample_count;
                     if (s_stop > s_end) s_stop = s_end;
                     c_pool = (s_stop - c_sbegin) * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
+#if RT_ITEM_SCALARS
+                    // (the item's values are the same in every lane; said so, they live in scalar registers instead of five of
+                    //  the 72 vector registers this kernel spills from)
+                    c_x0 = __builtin_amdgcn_readfirstlane(c_x0), c_band = __builtin_amdgcn_readfirstlane(c_band);
+                    c_sbegin = __builtin_amdgcn_readfirstlane(c_sbegin), c_pool = __builtin_amdgcn_readfirstlane(c_pool);
+#endif
                     cursor = 0;
                     mine = 0;
                     c_valid = true;
                     int hx_unused, hlr_unused;
                     home_pixel(c_x0, c_band, hx_unused, hlr_unused, c_hy, c_hvalid);
+#if RT_ITEM_SCALARS
+                    c_hvmask = __builtin_amdgcn_ballot_w64(c_hvalid != 0);
+#endif
                 }
             }
             bool start = false;
@@ -1439,7 +1452,14 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 sp = k & 63;
                 // row and validity of pixel sp live in lane sp's registers (all lanes take part)
                 spy = __shfl(c_hy, sp, 64);
+#if RT_ITEM_SCALARS
+                // (on-image bit of pixel sp from the item's lane mask: a select and a bit-field extract instead of a second
+                //  cross-lane read)
+                const uint32_t hv_word = (sp & 32) ? (uint32_t)(c_hvmask >> 32) : (uint32_t)c_hvmask;
+                const int pv = (int)((hv_word >> (sp & 31)) & 1u);
+#else
                 const int pv = __shfl(c_hvalid, sp, 64);
+#endif
                 spx = c_x0 + (sp & 7);
                 ss = c_sbegin + (k >> 6);
                 start = need && c_valid && k < c_pool && pv != 0;
