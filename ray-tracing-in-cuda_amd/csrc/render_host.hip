@@ -178,15 +178,11 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     L.cluster = csize;
     int off = 0;
     off += ns_slots + 4;  // sphere hot (+ never-hit padding)
-    L.off_box = off;
-    off += 2 * n_clusters;
     const int n_groups = (n_clusters + RT_GROUP - 1) / RT_GROUP;  // RT_GROUP consecutive clusters share an outer box
     L.ngr = n_groups;
     const int groups_per_window = 64 / RT_GROUP;  // one 64-bit cluster mask per window in the kernel
     const int n_windows = (n_groups + groups_per_window - 1) / groups_per_window;
     L.nwin = n_windows;
-    L.off_wbox = off;
-    off += 2 * n_windows;
     L.off_rect_hot = off;
     off += 2 * L.nr;
     L.off_cyl_hot = off;
@@ -217,9 +213,6 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
             if (!rest.empty() && ext[a] > 0.05f * big) axes |= 1 << a;
     }
     int n_axes = (axes & 1) + ((axes >> 1) & 1) + ((axes >> 2) & 1);
-    L.off_gbox = off;  // outer boxes: the box-hierarchy variants read them
-    off += 2 * n_groups;
-    L.hot_vec4 = off;  // what the box-hierarchy and flat-scan variants stage into LDS
     // ---- uniform grid over the clustered spheres (the default candidate search, CULL == 5: every lane walks the
     // cells its ray crosses front to back -- 3-D DDA -- and tests the spheres listed in them).
     // A sphere is listed in every cell its GROWN box touches.  The growth covers the fp32 error of the sphere test:
@@ -352,6 +345,15 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     L.off_grid_items = off;
     off += grid_wide ? ((int)grid_items.size() + 1 + 3) / 4 : ((int)grid_items.size() + 1 + 7) / 8;  // (+ 1: the pair test reads one entry past a list)
     L.hot_vec4_grid = off;  // what the grid-walk kernel stages into LDS
+    // the boxes of the cluster searches (the fallback for scenes without a grid, and ablations) lie behind the grid tables,
+    // so that the grid walk does not stage them (RTIOW: 2.5 KB of 15.2 KB)
+    L.off_box = off;
+    off += 2 * n_clusters;
+    L.off_wbox = off;
+    off += 2 * n_windows;
+    L.off_gbox = off;  // outer boxes: the box-hierarchy variants read them
+    off += 2 * n_groups;
+    L.hot_vec4 = off;  // what the box-hierarchy and flat-scan variants stage into LDS
     L.rt_axes = axes;
     L.rt_stride = 2 + n_axes * (RT_SLABS * RT_SLABS / 2);  // float4 records per window: {min, 1/width} + masks (2 per record)
     L.off_rtab = off;

@@ -83,6 +83,9 @@
 #ifndef RT_UNDEF_INIT
 #define RT_UNDEF_INIT 1
 #endif
+#ifndef RT_PARK_UNDEF
+#define RT_PARK_UNDEF 1
+#endif
 #ifndef RT_ITEM_SCALARS
 #define RT_ITEM_SCALARS 1
 #endif
@@ -408,7 +411,11 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     rng.g.x = rng.g.y = rng.g.z = 0u, rng.g.w = 1u, rng.draws = 0;
 
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, ra = 1, rinv_a = 1;
-    float beta_r = 1, beta_g = 1, beta_b = 1, L_r = 0, L_g = 0, L_b = 0;
+    // (no radiance accumulator: in this integrator a path collects radiance exactly once, in the event that ends it -- the sky
+    //  or the background on a miss, main.cpp:36-38 / main.cu:63, or an emitter, which never scatters, main.cu:48-58 -- so
+    //  ray_color's accumulated colour is throughput x that event's radiance, and a path that is absorbed, runs out of depth
+    //  or loses the roulette contributes exactly zero: nothing to add)
+    float beta_r = 1, beta_g = 1, beta_b = 1;
     int depth = 0;
     int cur_p = lane;  // tile-local pixel of the path this lane is tracing
     bool active = false;
@@ -423,13 +430,14 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     //   (6) the scatter step (lambertian / metal / dielectric) | the camera ray, then what both share: |d|^2, 1 / |d|^2
     // The loops of (5) cost max-over-lanes attempts each; as two loops (one inside the refill, one inside the shading)
     // they took 13 % of the frame (measured by cutting them out, RT_ABLATE=1).
-    bool ended = false;  // this lane's path ended in step (6) of the previous iteration: its sample is added in (3)
     // CULL == 5: ray parameter at which this lane's grid walk was cut short in the previous iteration (0: it was not);
     // the walk goes on from there in this one
     float t_res = 0.0f;
     for (;;) {
         tick(5);
         bool path_done = false;
+        float L_r = 0, L_g = 0, L_b = 0;  // the sample of a path that ends in this iteration
+        asm volatile("" : "=v"(L_r), "=v"(L_g), "=v"(L_b));  // (read by the lanes with path_done, which set them)
         // the winner's hit record, kept for the scatter step
         float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, inv_len = 0;
         int mat = 0, kind = -1;  // kind >= 0: a scatter step is due in (6)
@@ -526,6 +534,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
 #if RT_PREFIX_PARK
                 int p_idx = -1;
                 float p_hb = 0.0f, p_disc = 0.0f;
+#if RT_PARK_UNDEF
+                asm volatile("" : "=v"(p_hb), "=v"(p_disc));  // (read only where p_idx >= 0, which comes with their values)
+#endif
                 RT_SPHERE_PARK(s1, i + 1)
                 RT_SPHERE_PARK(s2, i + 2)
                 RT_SPHERE_PARK(s3, i + 3)
@@ -738,6 +749,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                             const float4 S = sph[idx], T = sph[jdx];
                             int p_idx = -1;
                             float p_hb = 0.0f, p_disc = 0.0f;
+#if RT_PARK_UNDEF
+                            asm volatile("" : "=v"(p_hb), "=v"(p_disc));
+#endif
                             RT_SPHERE_PARK(S, idx)
                             RT_SPHERE_PARK(T, jdx)
                             if (p_idx >= 0) resolve(p_idx, p_hb, p_disc);
@@ -1354,7 +1368,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const bool odd = kind == MK_LIGHT_CHECKER && checker_odd(px, py, pz);
                     float er = odd ? q2.x : q1.x, eg = odd ? q2.y : q1.y, eb = odd ? q2.z : q1.z;
                     if (EXT && kind == MK_LIGHT_IMAGE) er = tex_r, eg = tex_g, eb = tex_b;
-                    L_r = fmaf(er, beta_r, L_r), L_g = fmaf(eg, beta_g, L_g), L_b = fmaf(eb, beta_b, L_b);
+                    L_r = er * beta_r, L_g = eg * beta_g, L_b = eb * beta_b;
                     path_done = true;  // absorbed: main.cu:55-58
                     kind = -1;
                 }
@@ -1368,7 +1382,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 } else {
                     bg_r = P.background[0], bg_g = P.background[1], bg_b = P.background[2];
                 }
-                L_r = fmaf(beta_r, bg_r, L_r), L_g = fmaf(beta_g, bg_g, L_g), L_b = fmaf(beta_b, bg_b, L_b);
+                L_r = beta_r * bg_r, L_g = beta_g * bg_g, L_b = beta_b * bg_b;
                 path_done = true;
                 if (COUNT) c_misses++;
             }
@@ -1376,9 +1390,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
           }
         }
         tick(3);
-        // ---- (3) res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile; also for the lanes whose
-        // path ended in the scatter step of the previous iteration (absorbed by a metal, depth used up, roulette)
-        if (path_done || ended) {
+        // ---- (3) res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
+        if (path_done) {
             if (!(RT_ABLATE & 2)) {
                 const unsigned long long fr = radiance_to_fixed(L_r), fg = radiance_to_fixed(L_g), fb = radiance_to_fixed(L_b);
                 if (slot >= 0) {
@@ -1394,7 +1407,6 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 }
             }
             active = false;
-            ended = false;
         }
         tick(4);
         if (RT_PRIO_H != RT_PRIO_F) __builtin_amdgcn_s_setprio(RT_PRIO_F);
@@ -1521,7 +1533,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 if (POOL) exhausted = cursor >= c_pool;
                 else exhausted = __builtin_amdgcn_ballot_w64(c_hvalid != 0 && mine * 64 < c_pool) == 0ull;
             }
-            if (queue_empty && exhausted && !__any(ended)) {
+            if (queue_empty && exhausted) {
                 if (c_valid) flush_tile(c_acc, c_x0, c_band);
                 break;
             }
@@ -1627,9 +1639,9 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 dx = ndx, dy = ndy, dz = ndz;
                 depth--;
                 fresh = true;
-                ended = depth <= 0;  // main.cpp:42 / main.cu:69
+                if (depth <= 0) active = false;  // main.cpp:42 / main.cu:69: black
             } else {
-                ended = true;  // absorbed: main.cpp:32 / main.cu:55-58
+                active = false;  // absorbed: main.cpp:32 / main.cu:55-58: black
             }
         }
         // ---- (6b) the camera ray of the paths that start (camera::get_ray, camera.h:32-39)
@@ -1657,7 +1669,6 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 oy = c_org.y + offy;
                 oz = c_org.z + offz;
                 beta_r = beta_g = beta_b = 1.0f;
-                L_r = L_g = L_b = 0.0f;
                 depth = P.max_depth;
                 active = true;
                 fresh = true;
@@ -1674,12 +1685,11 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             if (started) {
                 if (rng_next<COUNT>(rng) > P.rr_p) active = false;
                 beta_r = beta_g = beta_b = 1.0f / P.rr_p;
-            } else if (fresh && !ended) {
-                if (rng_next<COUNT>(rng) > P.rr_p) ended = true;
+            } else if (fresh && active) {
+                if (rng_next<COUNT>(rng) > P.rr_p) active = false;
                 beta_r = beta_r / P.rr_p, beta_g = beta_g / P.rr_p, beta_b = beta_b / P.rr_p;
             }
         }
-        if (ended) active = false;  // no further query; its sample is added in step (3) of the next iteration
     }
 
     if (COUNT) {
@@ -1734,6 +1744,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
     if (i < n) out[i] = (float)((double)(long long)acc[i] * (1.0 / 16777216.0));
 }
 
+#ifdef RT_ISA_ONLY
+// tools/isa_stats.py: one instance alone (RT_ISA_ONLY = its template arguments), compiled to assembly in seconds
+template __global__ void render_kernel<RT_ISA_ONLY>(const RenderParams, const float4 *__restrict__, unsigned long long *__restrict__,
+                                                    unsigned int *__restrict__, DevCounters *__restrict__);
+#else
 // launchers used by render_host.hip
 // X(variant id, POOL, PREFETCH, SCALAR, CULL).  0 is the product default (the uniform-grid walk, CULL 5); the others are
 // ablations and fallbacks with identical results: bit 0 = no tile pool (strict one-lane-per-pixel), bit 1 = no LDS
@@ -1936,5 +1951,6 @@ int set_max_dynamic_lds(size_t bytes) {
 #undef RT_ATTR1
     return 0;
 }
+#endif  // RT_ISA_ONLY
 
 }  // namespace rtmi

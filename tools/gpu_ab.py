@@ -9,11 +9,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     spp, variant = int(sys.argv[2]), int(sys.argv[3])
     sc = rtmi.Scene.rtiow(7, 1920, 1080, spp, 50)
     o = rtmi.Opts(seed=2023, variant=variant)
-    sc.render(o)
+    import zlib
+    crc = zlib.crc32(sc.render(o).tobytes())
     ms = []
     for _ in range(3):
         st = rtmi.Stats(); sc.render(o, st); ms.append(st.kernel_ms)
-    print(f"{os.environ.get('RTMI_LIB', 'in-tree')}: variant {variant} {spp} spp: best {min(ms):.2f} ms, all {[round(m, 2) for m in ms]}", flush=True)
+    print(f"{os.environ.get('RTMI_LIB', 'in-tree')}: variant {variant} {spp} spp: best {min(ms):.2f} ms, all {[round(m, 2) for m in ms]}, image crc {crc:08x}", flush=True)
 else:
     spp, variant = sys.argv[1], sys.argv[2]
     for lib in sys.argv[3:]:
