@@ -269,10 +269,10 @@ def test_many_spheres_above_64k_lds(rtmi, rtcheck):
     sc.camera((0, 2, 12), (0, 0, 0), (0, 1, 0), 40.0)
     rng = np.random.default_rng(5)
     mats = [sc.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(8)] + [sc.metal((0.8, 0.8, 0.8), 0.1), sc.dielectric(1.5)]
-    for i in range(5000):
+    for i in range(3000):
         sc.sphere(rng.uniform(-6, 6, 3), float(rng.uniform(0.05, 0.2)), mats[i % len(mats)])
     _assert_same(rtmi, rtcheck, sc)              # default: global-memory tables at this size
-    _assert_same(rtmi, rtcheck, sc, variant=32)  # tables in LDS (105 KB: the raised dynamic-LDS limit)
+    _assert_same(rtmi, rtcheck, sc, variant=32)  # tables in LDS (about 120 KB with the grid tables in front of the boxes: the raised dynamic-LDS limit)
     _assert_same(rtmi, rtcheck, sc, variant=64)  # per-lane lists through the box hierarchy (global tables at this size)
 
 
