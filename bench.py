@@ -6,7 +6,11 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N rank processes itself (one per
-GPU, before this process touches the GPU) and fails if fewer than N devices are visible.
+GPU; this process never touches the GPU, each rank checks that its device exists).
+
+`--tiles-abi` times the multi-GPU path the C ABI exports instead: ONE process, rt_render_hip_tiles over
+`--gpus N` devices (one stream per device, ncclCommInitAll, ONE ncclGather, row placement, one copy to the
+caller's host buffer).  At N = 1 the default mode also reports it, next to the headline, under `extra`.
 
 One STEP = one full frame of the workload: every rank renders its interleaved row tiles
 with the HIP kernel (through the C ABI, into a torch tensor on torch's current stream),
@@ -96,18 +100,15 @@ def parse_args(argv=None):
     ap.add_argument("--verify", action="store_true", help="rank 0 also renders the unsharded frame and checks the "
                     "gathered one against it bit for bit (outside the timed region)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
+    ap.add_argument("--tiles-abi", action="store_true", help="one process: rt_render_hip_tiles (C ABI) over --gpus N devices")
     return ap.parse_args(argv)
 
 
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters, so no
-    process that has initialised HIP is ever re-executed) and wait for them.  The parent never touches the GPU."""
-    import torch  # device_count() does not initialise the runtime on this image
-    ndev = torch.cuda.device_count()
-    if args.backend == "nccl" and ndev < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible: refusing to run on fewer "
-              f"(use --backend gloo to rehearse ranks that share a GPU)", file=sys.stderr)
-        return 2
+    process that has initialised HIP is ever re-executed) and wait for them.  The parent never touches the GPU -- it does
+    not even count the devices: every rank checks LOCAL_RANK against what it sees and exits non-zero (main()), which fails
+    the whole run ("refusing to run on fewer"; --backend gloo rehearses ranks that share a GPU)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -126,6 +127,8 @@ def main():
     args = parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.tiles_abi:
+        sys.exit(tiles_abi_main(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
 
@@ -143,11 +146,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl" and world > 1:
+        raise SystemExit(f"bench.py rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible: refusing to run "
+                         f"--gpus {args.gpus} on fewer (use --backend gloo to rehearse ranks that share a GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    if local_rank >= ndev and args.backend == "nccl":
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
     dev_index = local_rank % ndev  # identity on a real N-GPU node; gloo rehearsals share GPUs
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -250,6 +254,10 @@ def main():
             result["roofline_linear_scan"] = linear_scan_leg(rtmi, scene, base, local, stream, torch, np)
         if world == 1 and not args.no_extra:
             result["extra"] = extra_configs(rtmi, dev_index, args.seed, local, stream, torch, np)
+            try:  # the multi-GPU path the C ABI exports, on this one GPU: what its plumbing costs per frame
+                result["extra"]["tiles_abi_1gpu"] = tiles_abi_frames(rtmi, scene, base, [dev_index], 3, np, reference=img.cpu().numpy())[0]
+            except Exception as e:  # never lose the bench line over an extra
+                result["extra"]["tiles_abi_1gpu"] = {"error": repr(e)}
         # ---- CPU baseline (reported only): the reference's own render() on this host's cores
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(rtmi, args)
@@ -258,6 +266,89 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def tiles_abi_frames(rtmi, scene, base, devices, steps, np, reference=None):
+    """rt_render_hip_tiles (include/rtmi.h; csrc/tiles.hip) on `devices`: the first call (streams, buffers, ncclCommInitAll)
+    apart, then `steps` frames.  Wall time per frame from call to return = render + gather + row placement + copy of the
+    frame to the caller's host buffer."""
+    o = rtmi.Opts(seed=base.seed, tile_rows=base.tile_rows, spp_chunk=base.spp_chunk, variant=base.variant)
+    st = rtmi.Stats()
+    t0 = time.perf_counter()
+    img = scene.render_tiles(devices=devices, opts=o, stats=st)
+    first = time.perf_counter() - t0
+    wall, kern, gath = [], [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        img = scene.render_tiles(devices=devices, opts=o, stats=st)
+        wall.append((time.perf_counter() - t0) * 1e3)
+        kern.append(st.kernel_ms), gath.append(st.gather_ms)
+    n = scene.width * scene.height * scene.spp
+    out = {"entry_point": "rt_render_hip_tiles", "devices": list(devices), "steps": steps,
+           "ms_per_frame_call_to_return": round(float(np.mean(wall)), 3),
+           "Msamples_per_s": round(n / (float(np.mean(wall)) * 1e-3) / 1e6, 1),
+           "slowest_device_render_ms": round(float(np.mean(kern)), 3),
+           "gather_placement_ms": round(float(np.mean(gath)), 3),
+           "first_call_s": round(first, 3),
+           "note": "host buffer out: includes the device-to-host copy of the fp32 frame; first_call_s = streams, buffers, "
+                   "ncclCommInitAll and one frame"}
+    if reference is not None:
+        out["equals_headline_frame"] = bool(np.array_equal(img, reference))
+        assert out["equals_headline_frame"], "rt_render_hip_tiles differs from the headline frame"
+    return out, img
+
+
+def tiles_abi_main(args) -> int:
+    """`bench.py --tiles-abi --gpus N`: the bench line of the single-process C-ABI path (no torch.distributed)."""
+    import numpy as np
+    from __graft_entry__ import load_package
+    rtmi = load_package()
+    try:
+        ndev = rtmi.device_count()
+    except rtmi.RtmiError:  # no HIP device at all
+        ndev = 0
+    if ndev < args.gpus:
+        print(f"bench.py --tiles-abi: --gpus {args.gpus} but only {ndev} GPU(s) visible: refusing to run on fewer", file=sys.stderr)
+        return 2
+    scene = rtmi.Scene.rtiow(7, args.width, args.height, args.spp, args.depth)
+    chunk = args.chunk if args.chunk >= 0 else 0
+    base = rtmi.Opts(seed=args.seed, tile_rows=args.tile_rows, spp_chunk=chunk, variant=args.variant)
+    devices = list(range(args.gpus))
+    st = rtmi.Stats()
+    img = scene.render_tiles(devices=devices, opts=base, stats=st)  # set-up: scene upload, streams, RCCL communicators
+    for _ in range(args.warmup):
+        img = scene.render_tiles(devices=devices, opts=base, stats=st)
+    kern, gath = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = scene.render_tiles(devices=devices, opts=base, stats=st)  # synchronous: returns with the frame in host memory
+        kern.append(st.kernel_ms), gath.append(st.gather_ms)
+    elapsed = time.perf_counter() - t0
+    n = scene.width * scene.height * scene.spp
+    result = {
+        "metric": "Msamples/sec (WxHxspp)", "value": round(n / (elapsed / args.steps) / 1e6, 3), "unit": "Msamples/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"RTIOW random-spheres scene (rt_scene_rtiow seed 7, {scene.info.num_prims} spheres), "
+                        f"{scene.width}x{scene.height}, {scene.spp} spp, depth {scene.max_depth}",
+            "sharding": f"rt_render_hip_tiles (C ABI, one process): row tiles of {args.tile_rows} rows interleaved over "
+                        f"{args.gpus} device(s), one stream per device, ONE ncclGather to device 0, row placement, one copy "
+                        f"to the caller's host buffer (inside the timed region: this entry point hands over host memory)",
+            "spp_chunk": chunk, "kernel_variant": args.variant, "render_seed": args.seed,
+            "slowest_device_render_ms": round(float(np.mean(kern)), 3), "gather_placement_ms": round(float(np.mean(gath)), 3),
+        },
+    }
+    if args.verify:
+        whole = scene.render(rtmi.Opts(seed=args.seed, spp_chunk=chunk, variant=args.variant))
+        same = bool(np.array_equal(whole, img))
+        result["config"]["gathered_equals_unsharded"] = same
+        assert same, "rt_render_hip_tiles differs from the unsharded frame"
+    mean = float(img.mean()) / scene.spp
+    result["config"]["frame_mean_radiance"] = round(mean, 5)
+    assert np.isfinite(mean) and 0.2 < mean < 0.8, mean
+    print(json.dumps(result), flush=True)
+    return 0
 
 
 def _git_head():
@@ -292,7 +383,7 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
         linear_flops = algorithmic_flops(c, types)
         per_query_linear = sum(F_TEST[int(t)] for t in types)
         n_other = sum(F_TEST[int(t)] for t in types if int(t) != 0)  # rects / cylinders / triangles: tested per query
-        culled = args.variant & 16 == 0
+        culled = args.variant not in (16, 17, 24)
         wq = max(1, c["wave_queries"])
         lanes = c["queries"] / wq  # live lanes per wave-level query
         if culled:
@@ -306,10 +397,11 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
         search = {5: ("uniform grid one cell high, per-lane x-z DDA over two-tier cell lists (default kernel; counted by the 3-D "
                       "walk's diagnostic kernel: same cells, same tests)") if c.get("grid_sheet") and args.variant in (0, 2)
                      else "uniform grid, per-lane 3-D DDA over two-tier cell lists (default kernel)",
-                  3: "candidate clusters from range tables, per-lane cluster lists", 4: "range tables, work-balanced cluster tests",
+                  7: "uniform grid over every primitive type, per-lane 3-D DDA over the wide cell lists",
+                  3: "candidate clusters from range tables, per-lane cluster lists",
                   2: "per-lane cluster lists through the two-level box hierarchy"}.get(c.get("cull_mode"), "clusters")
         roof["mode"] = f"culled hittable_list: {search}" if culled else "linear hittable_list scan (variant 16)"
-        if args.variant in (8, 32):  # the diagnostic kernel is the default one: its counts do not describe these
+        if args.variant == 32:  # the diagnostic kernel is the default one: its counts do not describe this one
             roof["mode"] = "ablation variant with wave-level cluster votes: no flop count"
             flops = flops_strict = 0
         if flops:
@@ -366,17 +458,13 @@ def executed_tests(c: dict, lanes: float):
     """Ray-primitive and box tests the default kernel's lanes execute, from the diagnostic counters.
     Returns (sphere tests, box tests, per-query set-up flops)."""
     q = c["queries"]
-    if c.get("cull_mode", 2) == 5:
+    if c.get("cull_mode", 2) in (5, 7):
         # uniform grid: every live lane tests the always-tested prefix and clips its ray against the grid's bounds (one box
         # test); lanes that reach it compute their entry cell and walk: one sphere test per list entry of every cell
         # visited (lane_clusters counts single spheres here), one step per further cell
         return (q * c["cull_prefix"] + c["lane_clusters"], q,
                 F_GRID_SETUP * q + (F_GRID_ENTER_SHEET if c.get("grid_sheet") else F_GRID_ENTER) * c["lane_groups"]
                 + F_GRID_STEP * c["lane_cands"])
-    if c.get("cull_mode", 2) == 4:
-        # work-balanced ablation: no per-cluster box tests; every candidate cluster's spheres are tested (by some lane)
-        return (q * c["cull_prefix"] + c["lane_clusters"] * c["cull_cluster_size"], q * c["cull_windows"],
-                F_CULL_SETUP * q + F_RANGE_LOOKUP * c["lane_groups"])
     if c.get("cull_mode", 2) == 3:
         # range tables: every live lane tests the always-tested prefix and clips its ray against every window box;
         # where it reaches one it looks its candidate clusters up (segment end points + slab indices: 24 flops),

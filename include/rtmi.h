@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 2
+#define RTMI_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -250,15 +250,17 @@ typedef struct rt_opts {
     int32_t spp_chunk;
     int32_t sample_first; /* render samples [sample_first, sample_first+count) */
     int32_t sample_count; /* 0 -> scene spp                                    */
-    uint32_t variant;     /* 0 = default kernel (uniform-grid walk); ablation and fallback builds (same results):
-                             bit 0 strict one-lane-per-pixel, bit 1 no LDS prefetch (linear scans), bit 3 tables in
-                             global memory, bit 4 no culling (linear scan of every sphere), bit 5 wave-level cluster
-                             votes, bit 6 per-lane cluster lists through the two-level box hierarchy (round 1's
-                             default), bit 7 per-lane cluster lists through the range tables (what scenes without a
-                             grid fall back to); 40 / 104 / 136 = variant 0 / 64 / 128 with all tables in global
-                             memory (what they switch to for scenes too large for LDS); 2 = variant 0 for a grid one
-                             cell high (walk along x and z only) and 44 = variant 40 over the wide grid tables of scenes
-                             with 65536 sphere slots or more: both picked by variant 0 itself */
+    uint32_t variant;     /* 0 = the product kernel for this scene, one of
+                               2  uniform-grid walk, compact tables in LDS, grid one cell high (walk along x and z: RTIOW)
+                               6  uniform-grid walk, compact tables in LDS (sphere-only scenes that fit LDS)
+                              36  uniform-grid walk over the wide tables in LDS: every primitive type is listed in the cells
+                              44  the same with the tables in global memory (scenes too large for LDS: no size limit)
+                             (rt_stats.kernel_variant reports the choice).  Libraries built with RTMI_ABLATIONS (the default
+                             build: rt_has_ablations()) also carry measurement variants with the same image, bit for bit:
+                               1 = 6 with strict one-lane-per-pixel ownership, 40 = 6 with its tables in global memory,
+                              16 = no culling (the reference's linear hittable_list scan), 17 = 16 with strict ownership,
+                              24 = 16 with the tables in global memory, 32 = wave-level cluster votes, 64 = per-lane cluster
+                              lists through a two-level box hierarchy, 128 = per-lane cluster lists through range tables */
 } rt_opts;
 
 typedef struct rt_stats {
@@ -299,6 +301,7 @@ typedef struct rt_stats {
     int32_t devices_used;
     int32_t grid_sheet;   /* rt_render_hip_count: 1 if the scene's grid is one cell high, i.e. the default kernel walks it along
                              x and z only (variant 2; the counting kernel itself walks in 3-D: same cells, same tests) */
+    int32_t kernel_variant; /* the kernel that ran: what variant 0 (or a counting call) resolved to */
 } rt_stats;
 
 void rt_opts_default(rt_opts *o);
@@ -395,6 +398,10 @@ int rt_abi_version(void);
 size_t rt_struct_size(int which);
 /* number of usable gfx950 devices, or -rt_status */
 int rt_device_count(void);
+/* 1 if this library carries the measurement variants of rt_opts.variant and the counting kernels of rt_render_hip_count
+ * (the default build; `make ABLATIONS=0` builds the six product kernels alone: same ABI, rt_render_hip_count then
+ * fails with RT_ERR_LIMIT and rt_opts.variant accepts 0, 2, 6, 36, 44) */
+int rt_has_ablations(void);
 /* Philox4x32-10 block (seeds every (pixel, sample) stream), for known-answer tests */
 void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* first n raw 32-bit words of the xorshift128 stream of one (pixel, sample); the kernel's

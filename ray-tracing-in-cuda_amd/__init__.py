@@ -108,6 +108,7 @@ class Stats(C.Structure):
         ("cull_clusters", C.c_int32), ("cull_groups", C.c_int32), ("cull_cluster_size", C.c_int32),
         ("wave_start_spread_us", C.c_double), ("wave_end_spread_us", C.c_double), ("wave_span_us", C.c_double),
         ("lane_cands", C.c_uint64), ("cull_mode", C.c_int32), ("cull_windows", C.c_int32), ("gather_ms", C.c_double), ("devices_used", C.c_int32), ("grid_sheet", C.c_int32),
+        ("kernel_variant", C.c_int32),
     ]
 
     def as_dict(self):
@@ -129,6 +130,7 @@ _f3 = C.POINTER(C.c_float)
 _sig("rt_last_error", C.c_char_p)
 _sig("rt_status_string", C.c_char_p, C.c_int)
 _sig("rt_abi_version", C.c_int)
+_sig("rt_has_ablations", C.c_int)
 _sig("rt_device_count", C.c_int)
 _sig("rt_struct_size", C.c_size_t, C.c_int)
 _sig("rt_opts_default", None, C.POINTER(Opts))
@@ -185,7 +187,7 @@ _sig("rt_aabb_hit", C.c_int, _f3, _f3, _f3, _f3, C.c_float, C.c_float)
 _sig("rt_sample_stream", None, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_int)
 
 C_SYMBOLS = [
-    "rt_last_error", "rt_status_string", "rt_abi_version", "rt_struct_size", "rt_device_count", "rt_opts_default",
+    "rt_last_error", "rt_status_string", "rt_abi_version", "rt_struct_size", "rt_device_count", "rt_has_ablations", "rt_opts_default",
     "rt_scene_load_json", "rt_scene_parse_json", "rt_scene_rtiow", "rt_scene_to_json", "rt_scene_free",
     "rt_scene_new", "rt_scene_set_background", "rt_scene_set_camera", "rt_scene_add_solid_color",
     "rt_scene_add_checker", "rt_scene_add_lambertian", "rt_scene_add_metal", "rt_scene_add_dielectric",
@@ -572,6 +574,11 @@ def struct_size(which: int) -> int:
 
 def abi_version() -> int:
     return _lib.rt_abi_version()
+
+
+def has_ablations() -> bool:
+    """Does the loaded library carry the measurement variants and the counting kernels (the default build)?"""
+    return bool(_lib.rt_has_ablations())
 
 
 LIB_PATH = _LIB_PATH

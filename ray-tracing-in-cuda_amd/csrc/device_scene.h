@@ -6,10 +6,10 @@
 //                                clusters of 8; padded with never-hit records (r*r = -inf)
 //     box     [ncl] 2 x float4   inflated bounding box of each cluster (culling variant)
 //     rect    [nr]  2 x float4   {a0, a1, b0, b1} {k, axis(bits), 0, 0}
-//     cyl     [nc]  4 x float4   m_inv rows 0..2, {radius^2, zmin, zmax, 0}
-//     cbox    [nc]  2 x float4   world-space bounding box of each cylinder (culling variant)
-//     tri     [nt]  3 x float4   {v1.xyz, n.x} {v2.xyz, n.y} {v3.xyz, n.z}   (n = unit normal, hittable.py:104)
-//     tbox    [nt]  2 x float4   bounding box of each triangle (culling variant)
+//     cyl     [nc]  6 x float4   m_inv rows 0..2, {radius^2, zmin, zmax, 0}, then the world-space bounding box of the open tube
+//                                {min.xyz, _} {max.xyz, _}: one run of records, so that a lane that finds the cylinder in a cell's
+//                                list has its box and its matrix in flight together
+//     tri     [nt]  5 x float4   {v1.xyz, n.x} {v2.xyz, n.y} {v3.xyz, n.z}   (n = unit normal, hittable.py:104), then its box
 //   COLD part (stays in global memory / L2; read once per bounce by the winning lane)
 //     sphere  [ns]  1 x float4   {1/r, material(bits), list index(bits), material kind(bits)}
 //     rect    [nr]  1 x float4   {material(bits), list index(bits), material kind(bits), 0}
@@ -24,6 +24,18 @@
 // root <= closest_so_far, gpu-version/object.cuh:23-37 with :61).
 #pragma once
 #include <stdint.h>
+
+// measurement variants, counting kernels and RTMI_* environment knobs (the default build); 0: the product kernels alone
+#ifndef RTMI_ABLATIONS
+#define RTMI_ABLATIONS 1
+#endif
+
+// spheres per cluster of the sphere table (a cluster occupies RT_CLUSTER + 1 slots, the last one never hit)
+#define RT_CLUSTER 8
+
+// records per cylinder / triangle of the hot tables: the primitive, then its bounding box (2 records)
+#define RT_CYL_STRIDE 6
+#define RT_TRI_STRIDE 5
 
 // consecutive clusters under one outer box
 #ifndef RT_GROUP
@@ -83,7 +95,10 @@ struct RenderParams {
     // scene image
     int32_t ns, nr, nc, nm;
     int32_t nt;              // triangles (grouped ids ns + nr + nc ...)
-    int32_t off_tri_hot, off_tbox, off_tri_cold;
+    // the leading rectangles / cylinders / triangles of their tables that are tested for every query (the oversized ones: a
+    // room's walls); the rest is listed in the cells of the wide grid tables.  The searches without a grid test all of them.
+    int32_t nr_a, nc_a, nt_a;
+    int32_t off_tri_hot, off_tri_cold;
     int32_t ns_pad;          // sphere slots incl. never-hit padding (= ns)
     int32_t np;              // leading slots that are always tested (big spheres), multiple of 8
     int32_t ncl;             // clusters of 8 slots after the prefix, each with a bounding box
@@ -91,7 +106,6 @@ struct RenderParams {
     int32_t off_box;         // 2 float4 per cluster: {min.xyz,_}, {max.xyz,_}
     int32_t ngr, off_gbox;   // outer boxes over RT_GROUP consecutive clusters
     int32_t nwin, off_wbox;  // window boxes over 64 consecutive clusters (64 / RT_GROUP outer boxes)
-    int32_t off_cbox;        // 2 float4 per cylinder: world-space bounding box of the open tube
     // range tables: per window {box min.xyz}, {1 / slab width .xyz}, then per enabled axis RT_SLABS^2 64-bit masks
     int32_t off_rtab, rt_stride, rt_axes;  // float4 offset, float4 records per window, enabled axes (bit a)
     // uniform grid over the clustered spheres (CULL == 5): 4 header records, cells (one 32-bit word each: first item << 8 |

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -23,10 +24,12 @@
 #endif
 namespace rtmi {
 
-void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
+bool launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
                    DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant, bool ext);
-int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster, bool ext);
+int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, bool ext);
 bool variant_has_ext(unsigned variant);
+bool variant_has_count(unsigned variant);
+bool has_ablations();
 void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStream_t stream);
 void launch_item_params(unsigned int *queue, const ItemParams &ip, hipStream_t stream);
 int set_max_dynamic_lds(size_t bytes);
@@ -84,8 +87,27 @@ static inline float bits(int32_t v) {
     return f;
 }
 
+// LDS left for a workgroup's hot tables beside full occupancy (RT_WAVES_PER_SIMD workgroups per CU), after one 64-pixel
+// rgb accumulator per wave
+static constexpr size_t kAccLds = 4 * 192 * sizeof(unsigned long long);
+static constexpr size_t kLdsTableBytes = (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - kAccLds;
+
+#if RTMI_ABLATIONS
+// measurement knobs of the default build (tests, bench.py, tools/): read once; the product build (make ABLATIONS=0) has none
+static double knob(const char *name, double fallback) {
+    const char *e = getenv(name);
+    return e ? atof(e) : fallback;
+}
+static bool knob_set(const char *name) { return getenv(name) != nullptr; }
+#else
+static constexpr double knob(const char *, double fallback) { return fallback; }
+static constexpr bool knob_set(const char *) { return false; }
+#endif
+
 // ---- scene tables -> device image ------------------------------------------------
-static void pack_scene(const Scene &s, DeviceSceneCache &c) {
+// forced: primitives that must be tested for every query whatever their size (members of a cell whose list overflowed in an
+// earlier attempt).  Returns false, with more primitives added to `forced`, when a cell's list overflows.
+static bool pack_scene_once(const Scene &s, DeviceSceneCache &c, std::vector<char> &forced) {
     std::vector<int> sph, rec, cyl, tri;
     for (size_t i = 0; i < s.prims.size(); ++i) {
         switch (s.prims[i].type) {
@@ -95,30 +117,34 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         default: rec.push_back((int)i); break;
         }
     }
+    const bool sphere_only = rec.empty() && cyl.empty() && tri.empty() && s.images.empty();
     // Sphere slots.  The closest hit does not depend on the visiting order (ties are resolved
     // through the stored list index), so the table is laid out for the kernel:
     //   prefix   : the big spheres (|r| > 4 x median), largest first -- the likeliest closest
     //              hits, tested unconditionally, so best_t is tight before anything else;
-    //   clusters : the rest in Morton order of their centres, 8 per cluster, each cluster with a
-    //              bounding box (the slab test of aabb.hpp) the culling variant tests first.
-    // Both parts are padded to multiples of 8 with never-hit records (r*r = -inf), plus 4 more.
+    //   clusters : the rest in Morton order of their centres, 8 per cluster (what the grid's cells list; the clusters
+    //              and their boxes serve the cluster searches of the ablation builds and the scan of far origins).
+    // Both parts are padded with never-hit records (r*r = -inf).
     std::stable_sort(sph.begin(), sph.end(), [&](int a, int b) {
         return std::fabs(s.prims[a].f[3]) > std::fabs(s.prims[b].f[3]);
     });
     std::vector<int> slots;  // prim index per slot, -1 = padding
-    int n_prefix = (int)sph.size();
-    if (sph.size() > 16) {
-        std::vector<float> radii;
-        for (int i : sph) radii.push_back(std::fabs(s.prims[i].f[3]));
-        std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
-        const float big = 4.0f * radii[radii.size() / 2];
-        n_prefix = 0;
-        while (n_prefix < (int)sph.size() && std::fabs(s.prims[sph[n_prefix]].f[3]) > big) ++n_prefix;
+    std::vector<int> rest;
+    {
+        float big = 0.0f;  // 0: every sphere is tested for every query (16 spheres or fewer)
+        if (sph.size() > 16) {
+            std::vector<float> radii;
+            for (int i : sph) radii.push_back(std::fabs(s.prims[i].f[3]));
+            std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+            big = 4.0f * radii[radii.size() / 2];
+        }
+        for (int i : sph) {
+            if (big == 0.0f || std::fabs(s.prims[i].f[3]) > big || forced[i]) slots.push_back(i);
+            else rest.push_back(i);
+        }
     }
-    for (int k = 0; k < n_prefix; ++k) slots.push_back(sph[k]);
     while (slots.size() % 4) slots.push_back(-1);  // the prefix is walked four records at a time
     const int np_slots = (int)slots.size();
-    std::vector<int> rest(sph.begin() + n_prefix, sph.end());
     if (!rest.empty()) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int i : rest)
@@ -141,23 +167,12 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         };
         std::stable_sort(rest.begin(), rest.end(), [&](int a, int b) { return morton(a) < morton(b); });
     }
-    // Spheres per cluster: the size whose Morton block is the most compact.  Spheres spread over a surface
-    // (RTIOW's small spheres on the ground: the centres' bound is flat) fall into square blocks of 16 = 4 x 4
-    // rather than 2 x 4 (230 vs 237 ms); spheres filling a volume into cubes of 8 = 2 x 2 x 2 rather than
-    // 2 x 2 x 4 (random clouds 20 %, the DNA scene 6 % faster with 8).  RTMI_CLUSTER=8|16 overrides.
-    // Spheres per cluster.  8 everywhere: with the candidate clusters looked up in the range tables, the per-cluster
-    // box tests no longer pay for themselves by being few (RTIOW: 53.5 ms with 8 against 55.4 ms with 16 per 256 spp;
-    // the box hierarchy of round 1 preferred 4 x 4 blocks of 16 on sheet-like scenes).  RTMI_CLUSTER=16 keeps the
-    // other build reachable for measurements.
-    int csize = 8;
-    if (const char *e = getenv("RTMI_CLUSTER")) {
-        if (atoi(e) == 16) csize = 16;
-    }
-    // Cluster q occupies the slots [np + q (csize + 1), + csize) followed by ONE never-hit slot: with a stride of
-    // csize + 1 records, record h of clusters q and q' lies (q - q') records apart modulo 16, so the lanes of a wave
-    // that walk different clusters read different LDS banks with the same instruction (a ds_read_b128 serves 16
-    // lanes per cycle, one 16-byte record per 4 banks; with stride 16 every cluster's record h shared one bank group:
-    // 19.5 % of the LDS cycles were conflicts).  All-padding clusters end the table (read-ahead of the flat scans).
+    // Cluster q occupies the slots [np + 9 q, + 8) followed by ONE never-hit slot: with a stride of 9 records, record h of
+    // clusters q and q' lies (q - q') records apart modulo 16, so the lanes of a wave that read different clusters hit
+    // different LDS banks with the same instruction (a ds_read_b128 serves 16 lanes per cycle, one 16-byte record per 4
+    // banks; with stride 16 every cluster's record h shared one bank group: 19.5 % of the LDS cycles were conflicts).
+    // All-padding clusters end the table (read-ahead of the flat scan; the pair test's never-hit partner).
+    const int csize = RT_CLUSTER;
     const int n_clusters = ((int)rest.size() + csize - 1) / csize;
     const int cstride = csize + 1;
     for (int q = 0; q < n_clusters + 3; ++q)  // + 3 all-padding clusters: the flat scan reads 16 records a step and one ahead
@@ -168,14 +183,97 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     while (slots.size() % 4) slots.push_back(-1);
     const int ns_slots = (int)slots.size();
 
+    // ---- world boxes of the other primitives (double precision; grown below where they are listed)
+    struct OBox {
+        double lo[3], hi[3];
+    };
+    auto rect_box = [&](const rt_prim &p) {
+        OBox b;
+        const int axis = p.type - RT_PRIM_XY_RECT;  // 0: z = k (x, y extents), 1: y = k (x, z), 2: x = k (y, z)
+        const int ia = axis == 2 ? 1 : 0, ib = axis == 0 ? 1 : 2, ik = axis == 0 ? 2 : (axis == 1 ? 1 : 0);
+        b.lo[ia] = std::min(p.f[0], p.f[1]), b.hi[ia] = std::max(p.f[0], p.f[1]);
+        b.lo[ib] = std::min(p.f[2], p.f[3]), b.hi[ib] = std::max(p.f[2], p.f[3]);
+        b.lo[ik] = b.hi[ik] = p.f[4];
+        return b;
+    };
+    // cylinders: world box of the open tube = union of the boxes of its two end circles
+    // (centre M (0,0,z), radius R, normal = the tube axis a: half-extent R sqrt(1 - a_i^2) on axis i)
+    auto cyl_box = [&](const rt_prim &p, double R, double zpad) {
+        OBox b;
+        double ax[3] = {p.m[2], p.m[6], p.m[10]};  // image of the object z axis
+        const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        const double z0 = std::min((double)p.f[1], (double)p.f[2]) - zpad, z1 = std::max((double)p.f[1], (double)p.f[2]) + zpad;
+        for (int a = 0; a < 3; ++a) {
+            const double ai = an > 0 ? ax[a] / an : 0.0;
+            const double half = R * std::sqrt(std::max(0.0, 1.0 - ai * ai));
+            const double c0 = p.m[a * 4 + 2] * z0 + p.m[a * 4 + 3];
+            const double c1 = p.m[a * 4 + 2] * z1 + p.m[a * 4 + 3];
+            b.lo[a] = std::min(c0, c1) - half, b.hi[a] = std::max(c0, c1) + half;
+        }
+        return b;
+    };
+    auto tri_box = [&](const rt_prim &p) {
+        OBox b;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = std::min((double)p.m[a], std::min((double)p.m[3 + a], (double)p.m[6 + a]));
+            b.hi[a] = std::max((double)p.m[a], std::max((double)p.m[3 + a], (double)p.m[6 + a]));
+        }
+        return b;
+    };
+    std::vector<int> others;  // rects, cylinders, triangles: prim indices
+    others.insert(others.end(), rec.begin(), rec.end());
+    others.insert(others.end(), cyl.begin(), cyl.end());
+    others.insert(others.end(), tri.begin(), tri.end());
+    std::vector<int> oidx(s.prims.size(), -1);  // position of a primitive in `others`
+    for (size_t k = 0; k < others.size(); ++k) oidx[others[k]] = (int)k;
+    std::vector<OBox> obox(others.size());
+    for (size_t k = 0; k < others.size(); ++k) {
+        const rt_prim &p = s.prims[others[k]];
+        obox[k] = p.type == RT_PRIM_CYLINDER ? cyl_box(p, std::fabs((double)p.f[0]), 0.0) : (p.type == RT_PRIM_TRIANGLE ? tri_box(p) : rect_box(p));
+    }
+    // Which of them go into the grid's cells?  Like the spheres: none while the scene is small (16 primitives outside the
+    // sphere prefix or fewer: the per-query loops are the cheaper search), and not the oversized ones (largest box edge > 8 x
+    // the median of what would be listed: a room's walls, a ground plane), which every ray has to test anyway.
+    std::vector<char> listed(others.size(), 0);
+    if (rest.size() + others.size() > 16) {
+        std::vector<double> sizes;
+        for (int i : rest) sizes.push_back(2.0 * std::fabs((double)s.prims[i].f[3]));
+        auto edge = [&](size_t k) {
+            return std::max(obox[k].hi[0] - obox[k].lo[0], std::max(obox[k].hi[1] - obox[k].lo[1], obox[k].hi[2] - obox[k].lo[2]));
+        };
+        for (size_t k = 0; k < others.size(); ++k) sizes.push_back(edge(k));
+        std::nth_element(sizes.begin(), sizes.begin() + sizes.size() / 2, sizes.end());
+        const double big = 8.0 * sizes[sizes.size() / 2];
+        for (size_t k = 0; k < others.size(); ++k) listed[k] = (edge(k) <= big || !(big > 0.0)) && !forced[others[k]];
+    }
+    // the other primitives' tables: the always-tested ones first (the kernel's per-query loops run over that prefix)
+    auto order_table = [&](std::vector<int> &v, int &n_always) {
+        std::vector<int> a, b;
+        for (int i : v) (listed[oidx[i]] ? b : a).push_back(i);
+        n_always = (int)a.size();
+        v = a;
+        v.insert(v.end(), b.begin(), b.end());
+    };
     RenderParams &L = c.layout;
     memset(&L, 0, sizeof L);
+    {
+        int na = 0;
+        order_table(rec, na), L.nr_a = na;
+        order_table(cyl, na), L.nc_a = na;
+        order_table(tri, na), L.nt_a = na;
+    }
     L.ns = ns_slots, L.nr = (int)rec.size(), L.nc = (int)cyl.size(), L.nm = (int)s.mats.size();
     L.nt = (int)tri.size();
     L.ns_pad = ns_slots;
     L.np = np_slots;
     L.ncl = n_clusters;
     L.cluster = csize;
+    // grouped id of an other primitive: its position in the reordered tables behind the sphere slots
+    std::vector<int> gid_of(s.prims.size(), -1);
+    for (size_t k = 0; k < rec.size(); ++k) gid_of[rec[k]] = ns_slots + (int)k;
+    for (size_t k = 0; k < cyl.size(); ++k) gid_of[cyl[k]] = ns_slots + L.nr + (int)k;
+    for (size_t k = 0; k < tri.size(); ++k) gid_of[tri[k]] = ns_slots + L.nr + L.nc + (int)k;
+
     int off = 0;
     off += ns_slots + 4;  // sphere hot (+ never-hit padding)
     const int n_groups = (n_clusters + RT_GROUP - 1) / RT_GROUP;  // RT_GROUP consecutive clusters share an outer box
@@ -186,20 +284,15 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     L.off_rect_hot = off;
     off += 2 * L.nr;
     L.off_cyl_hot = off;
-    off += 4 * L.nc;
-    L.off_cbox = off;
-    off += 2 * L.nc;
+    off += RT_CYL_STRIDE * L.nc;  // (each followed by its box)
     L.off_tri_hot = off;
-    off += 3 * L.nt;
-    L.off_tbox = off;
-    off += 2 * L.nt;
+    off += RT_TRI_STRIDE * L.nt;
     L.off_cam = off;  // camera::camera's derived vectors (camera.h:9-31): read once per new sample
     off += 6;
-    // Range tables (candidate clusters of a ray segment without testing every box): per window of 64 clusters and
-    // per enabled axis, R[i0 * 16 + i1] = the clusters whose box overlaps the slabs i0..i1 of the window box cut
-    // into RT_SLABS slabs along that axis (64-bit mask).  The clusters a ray can reach are a subset of
-    // R_x[..] & R_y[..] & R_z[..] taken at the slab ranges of the segment's bounding box.  An axis along which the
-    // clustered spheres do not spread (a sheet: RTIOW's y) carries no information and is left out (2 KB of LDS).
+    // Range tables (ablation variant 128: candidate clusters of a ray segment without testing every box): per window of 64
+    // clusters and per enabled axis, R[i0 * 16 + i1] = the clusters whose box overlaps the slabs i0..i1 of the window box cut
+    // into RT_SLABS slabs along that axis (64-bit mask).  An axis along which the clustered spheres do not spread (a sheet:
+    // RTIOW's y) carries no information and is left out (2 KB of LDS).
     int axes = 0;
     {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -213,130 +306,233 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
             if (!rest.empty() && ext[a] > 0.05f * big) axes |= 1 << a;
     }
     int n_axes = (axes & 1) + ((axes >> 1) & 1) + ((axes >> 2) & 1);
-    // ---- uniform grid over the clustered spheres (the default candidate search, CULL == 5: every lane walks the
-    // cells its ray crosses front to back -- 3-D DDA -- and tests the spheres listed in them).
-    // A sphere is listed in every cell its GROWN box touches.  The growth covers the fp32 error of the sphere test:
-    // |disc_fp32 - disc| <= K eps a |oc|^2 (K = 32 bounds the operation-by-operation sum, about 15 eps |oc|^2), so a
-    // ray the fp32 test can accept passes within r' = sqrt(r^2 + K eps |oc|^2) of the centre, and its fp32 hit point lies
-    // inside that ball too.  |oc| <= |o| + |c|, so the growth depends on how far from the coordinate origin a ray starts;
-    // the lists come in two tiers:
-    //   near  |o| <= ob_near (the cloud, the camera; RTIOW 23.4): the first n_near entries of a cell's list
-    //   far   |o| <= ob_far  (hits on distant ground; 8x the cloud, at least 64): all n_all entries
-    // and lanes further out still test the grid's bounds with the per-lane margin of the box tests and, if they can reach
-    // it at all, scan every clustered sphere: rare, and the flat scan is the definition of the result.
+    // ---- uniform grid (the candidate search: every lane walks the cells its ray crosses front to back -- 3-D DDA -- and tests
+    // what they list).  A primitive is listed in every cell its GROWN box touches.  The growth covers the fp32 error of its
+    // test, so that the walk finds every hit the linear scan would find:
+    //   spheres: |disc_fp32 - disc| <= K eps a |oc|^2 (K = 32 bounds the operation-by-operation sum, about 15 eps |oc|^2), so a
+    //     ray the fp32 test can accept passes within r' = sqrt(r^2 + K eps |oc|^2) of the centre, and its fp32 hit point lies
+    //     inside that ball too.  |oc| <= |o| + |c|, so the growth depends on how far from the coordinate origin a ray starts;
+    //     the lists come in two tiers:
+    //       near  |o| <= ob_near (the cloud, the camera; RTIOW 23.4): the first n_near entries of a cell's list
+    //       far   |o| <= ob_far  (hits on distant ground; 8x the cloud, at least 64): all n_all entries
+    //   cylinders (object.cuh:233-290): the same quadratic in the tube's object space, K = 64 (the transform's rounding rides
+    //     along): tube radius R' = sqrt(R^2 + K eps (ob_far + |corner|)^2), ends moved out by the term below;
+    //   rectangles, triangles: the accepted point lies on the ray within a few eps (|o| + |p|) of the primitive's plane (the
+    //     triangle's plane point r = o - d/|d| (oc.n)/theta carries the error of oc.n, which does not grow with 1/theta) and, in
+    //     projection, inside its outline to the same order: 64 eps (ob_far + |corner|);
+    //   one tier (the far one) for these three: their growth is 1e-4 of a cell.
+    // Lanes further out than ob_far test the grid's bounds with the per-lane margin of the box tests and, if they can reach it
+    // at all, test everything the cells list: rare, and the flat scan is the definition of the result.
     // (0.004 cell + 1e-5 (max|c| + 1)) more covers the walk's own rounding: the entry point, the cell boundaries, up to
-    // 255 accumulated leave distances.)
-    std::vector<uint32_t> grid_cells;   // (first item << 12) | (n_near << 6) | n_all;  wide: {first item, (n_near << 8) | n_all} per cell
-    std::vector<uint32_t> grid_items;   // sphere slots; a cell's near-tier entries first (stored as 16-bit words unless wide)
-    bool grid_wide = false;
+    // 1023 accumulated leave distances.)
+    // Two table formats: COMPACT (sphere-only scenes that fit LDS: 16-bit entries, one word per cell, <= 255 cells per axis,
+    // <= 63 entries per cell) and WIDE (everything else: 32-bit entries, two words per cell, <= 1023 cells per axis, <= 1023
+    // sphere entries per tier and <= 4095 other entries per cell).
+    std::vector<uint32_t> grid_cells;   // compact: (first item << 12) | (n_near << 6) | n_all;  wide: {first item, n_near | n_all << 10 | n_other << 20}
+    std::vector<uint32_t> grid_items;   // sphere slots (a cell's near-tier entries first), then grouped ids of the other primitives
+    bool grid_wide = !sphere_only || ns_slots >= 65536;
     float grid_min[3] = {0, 0, 0}, grid_size[3] = {1, 1, 1};
     int grid_n[3] = {0, 0, 0};
     float grid_ob2[2] = {0.0f, 0.0f}, grid_shrink = 0.0f;
-    {
-        static const double cell_factor = getenv("RTMI_GRID_CELL") ? atof(getenv("RTMI_GRID_CELL")) : 1.0;
-        static const double ob_env = getenv("RTMI_GRID_OB") ? atof(getenv("RTMI_GRID_OB")) : 0.0;  // experiments
-        // 65536 sphere slots or more: the WIDE table format (32-bit list entries, 64-bit cell words, up to 1023 cells per
-        // axis and 255 entries per cell), read from global memory by its own kernel instance (CULL == 7, variant 44)
-        grid_wide = ns_slots >= 65536;
-        bool ok = !rest.empty();
+    std::vector<OBox> listed_box(others.size());  // grown boxes of the listed others (also what their box tests read)
+    size_t n_listed = rest.size();
+    for (size_t k = 0; k < others.size(); ++k) n_listed += listed[k] ? 1 : 0;
+    bool overflow = false;
+    for (int attempt = 0; attempt < 2 && n_listed > 0; ++attempt) {
+        const double cell_factor = knob("RTMI_GRID_CELL", 1.0);
+        const double ob_env = knob("RTMI_GRID_OB", 0.0);  // experiments
+        grid_cells.clear(), grid_items.clear();
         const double max_dim = grid_wide ? 1023.0 : 255.0;
         const long long max_cells = grid_wide ? (1LL << 21) : (1LL << 18);
-        const size_t max_per_cell = grid_wide ? 255 : 63;
+        const size_t max_per_cell = grid_wide ? 1023 : 63, max_other = 4095;
         const size_t max_items = grid_wide ? ((size_t)1 << 30) : ((size_t)1 << 20);
+        // centres (spheres) and box centres (others): the cloud the cells are sized for
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, cmax = 0.0, cmax2 = 0.0;
-        for (int i : rest) {
+        double slo[3] = {1e300, 1e300, 1e300}, shi[3] = {-1e300, -1e300, -1e300};  // of the sphere centres alone
+        auto add_point = [&](const double *c) {
             double c2 = 0.0;
             for (int a = 0; a < 3; ++a) {
-                const double c = (double)s.prims[i].f[a];
-                lo[a] = std::min(lo[a], c), hi[a] = std::max(hi[a], c);
-                cmax = std::max(cmax, std::fabs(c)), c2 += c * c;
+                lo[a] = std::min(lo[a], c[a]), hi[a] = std::max(hi[a], c[a]);
+                cmax = std::max(cmax, std::fabs(c[a])), c2 += c[a] * c[a];
             }
             cmax2 = std::max(cmax2, std::sqrt(c2));
+        };
+        for (int i : rest) {
+            const double c[3] = {s.prims[i].f[0], s.prims[i].f[1], s.prims[i].f[2]};
+            add_point(c);
+            for (int a = 0; a < 3; ++a) slo[a] = std::min(slo[a], c[a]), shi[a] = std::max(shi[a], c[a]);
         }
-        if (ok) {
-            const double cam = std::sqrt(s.cam.lookfrom[0] * s.cam.lookfrom[0] + s.cam.lookfrom[1] * s.cam.lookfrom[1] +
-                                         s.cam.lookfrom[2] * s.cam.lookfrom[2]) + std::fabs(s.cam.aperture);
-            const double ob_near = ob_env > 0.0 ? ob_env : std::max(1.5 * cmax2, 1.1 * cam + 1.0);
-            const double ob_far = std::max(std::max(64.0, 8.0 * cmax2), 4.0 * ob_near);
-            grid_ob2[0] = (float)(ob_near * ob_near * (1.0 - 1e-5)), grid_ob2[1] = (float)(ob_far * ob_far * (1.0 - 1e-5));
-            double ext[3], big = 0.0;
-            for (int a = 0; a < 3; ++a) ext[a] = hi[a] - lo[a], big = std::max(big, ext[a]);
-            int dims = 0;
-            double measure = 1.0;
-            bool spread[3];
+        for (size_t k = 0; k < others.size(); ++k) {
+            if (!listed[k]) continue;
+            const double c[3] = {0.5 * (obox[k].lo[0] + obox[k].hi[0]), 0.5 * (obox[k].lo[1] + obox[k].hi[1]), 0.5 * (obox[k].lo[2] + obox[k].hi[2])};
+            add_point(c);
+            // (the far corners count towards the reach of the tiers: |oc| <= |o| + |corner|)
+            double far2 = 0.0;
             for (int a = 0; a < 3; ++a) {
-                spread[a] = ext[a] > 0.05 * big;
-                if (spread[a]) ++dims, measure *= ext[a];
+                const double m = std::max(std::fabs(obox[k].lo[a]), std::fabs(obox[k].hi[a]));
+                far2 += m * m, cmax = std::max(cmax, m);
             }
-            // cell edge: a multiple of the spacing of the centres.  Measured: RTIOW (a sheet, one sphere per unit square)
-            // 1.0 / 1.25 / 1.5 / 2.0 x -> 41.5 / 39.9 / 42.0 / 42.0 ms per 256 spp; 4000 spheres in a volume 0.7 / 1.0 /
-            // 1.4 x -> 6.4 / 6.7 / 7.3 ms, 20000: 12.3 / 12.7 / 15.1 ms (RTMI_GRID_CELL scales the choice).
-            double cell = dims ? std::pow(measure / (double)rest.size(), 1.0 / dims) * (dims == 3 ? 0.85 : 1.25) * cell_factor : 1.0;
-            if (!(cell > 0.0)) cell = 1.0;
-            std::vector<double> grow_near(rest.size()), grow_far(rest.size());
-            double rmax_near = 0.0, rmax_far = 0.0;
-            for (;;) {
-                rmax_near = rmax_far = 0.0;
-                for (size_t k = 0; k < rest.size(); ++k) {
-                    const float *sp = s.prims[rest[k]].f;
-                    const double r = std::fabs((double)sp[3]);
-                    const double cn = std::sqrt((double)sp[0] * sp[0] + (double)sp[1] * sp[1] + (double)sp[2] * sp[2]);
-                    const double K = 32.0 * std::ldexp(1.0, -24), walk = 4e-3 * cell + 1e-5 * (cmax + 1.0);
-                    grow_near[k] = std::sqrt(r * r + K * (ob_near + cn) * (ob_near + cn)) + walk;
-                    grow_far[k] = std::sqrt(r * r + K * (ob_far + cn) * (ob_far + cn)) + walk;
-                    rmax_near = std::max(rmax_near, grow_near[k]), rmax_far = std::max(rmax_far, grow_far[k]);
-                }
-                long long total = 1;
-                for (int a = 0; a < 3; ++a) {
-                    const double span = ext[a] + 2.0 * rmax_far;
-                    grid_n[a] = spread[a] ? (int)std::min(max_dim, std::max(1.0, std::ceil(span / cell))) : 1;
-                    grid_min[a] = (float)(lo[a] - rmax_far);
-                    grid_size[a] = (float)(span / grid_n[a]);
-                    total *= grid_n[a];
-                }
-                if (total <= max_cells) break;
-                cell *= 1.3;
-            }
-            // near-tier lanes clip their rays to the bounds of the near-tier boxes: the far tier's, this much further in
-            grid_shrink = (float)((rmax_far - rmax_near) * (1.0 - 1e-6));
-            const int nx = grid_n[0], ny = grid_n[1], nz = grid_n[2];
-            std::vector<std::vector<uint32_t>> lists((size_t)nx * ny * nz), extra((size_t)nx * ny * nz);
+            cmax2 = std::max(cmax2, std::sqrt(far2));
+        }
+        const double cam = std::sqrt(s.cam.lookfrom[0] * s.cam.lookfrom[0] + s.cam.lookfrom[1] * s.cam.lookfrom[1] +
+                                     s.cam.lookfrom[2] * s.cam.lookfrom[2]) + std::fabs(s.cam.aperture);
+        const double ob_near = ob_env > 0.0 ? ob_env : std::max(1.5 * cmax2, 1.1 * cam + 1.0);
+        const double ob_far = std::max(std::max(64.0, 8.0 * cmax2), 4.0 * ob_near);
+        grid_ob2[0] = (float)(ob_near * ob_near * (1.0 - 1e-5)), grid_ob2[1] = (float)(ob_far * ob_far * (1.0 - 1e-5));
+        double ext[3], big = 0.0;
+        for (int a = 0; a < 3; ++a) ext[a] = hi[a] - lo[a], big = std::max(big, ext[a]);
+        int dims = 0;
+        double measure = 1.0;
+        bool spread[3];
+        for (int a = 0; a < 3; ++a) {
+            spread[a] = ext[a] > 0.05 * big;
+            if (spread[a]) ++dims, measure *= ext[a];
+        }
+        // cell edge: a multiple of the spacing of the centres.  Measured: RTIOW (a sheet, one sphere per unit square)
+        // 1.0 / 1.25 / 1.5 / 2.0 x -> 41.5 / 39.9 / 42.0 / 42.0 ms per 256 spp; 4000 spheres in a volume 0.7 / 1.0 /
+        // 1.4 x -> 6.4 / 6.7 / 7.3 ms, 20000: 12.3 / 12.7 / 15.1 ms (RTMI_GRID_CELL scales the choice).
+        double cell = dims ? std::pow(measure / (double)n_listed, 1.0 / dims) * (dims == 3 ? 0.85 : 1.25) * cell_factor : 1.0;
+        if (!(cell > 0.0)) cell = 1.0;
+        std::vector<double> grow_near(rest.size()), grow_far(rest.size());
+        double rmax_near = 0.0, rmax_far = 0.0;
+        double blo[3], bhi[3], nlo[3], nhi[3];  // bounds of the far-tier boxes (the grid's), of the near-tier boxes
+        const double eps = std::ldexp(1.0, -24);
+        for (;;) {
+            rmax_near = rmax_far = 0.0;
+            const double walk = 4e-3 * cell + 1e-5 * (cmax + 1.0);
             for (size_t k = 0; k < rest.size(); ++k) {
-                // the slot of this sphere: clusters of csize behind the prefix, one padding slot per cluster
-                const int slot = np_slots + (int)(k / csize) * cstride + (int)(k % csize);
-                int c0[3], c1[3], n0[3], n1[3];
-                for (int a = 0; a < 3; ++a) {
-                    const double c = (double)s.prims[rest[k]].f[a];
-                    auto cell_of = [&](double x) {
-                        const int i = (int)std::floor((x - (double)grid_min[a]) / (double)grid_size[a]);
-                        return std::min(std::max(i, 0), grid_n[a] - 1);
-                    };
-                    c0[a] = cell_of(c - grow_far[k]), c1[a] = cell_of(c + grow_far[k]);
-                    n0[a] = cell_of(c - grow_near[k]), n1[a] = cell_of(c + grow_near[k]);
-                }
-                for (int iz = c0[2]; iz <= c1[2]; ++iz)
-                    for (int iy = c0[1]; iy <= c1[1]; ++iy)
-                        for (int ix = c0[0]; ix <= c1[0]; ++ix) {
-                            const bool near = ix >= n0[0] && ix <= n1[0] && iy >= n0[1] && iy <= n1[1] && iz >= n0[2] && iz <= n1[2];
-                            (near ? lists : extra)[((size_t)iz * ny + iy) * nx + ix].push_back((uint32_t)slot);
-                        }
+                const float *sp = s.prims[rest[k]].f;
+                const double r = std::fabs((double)sp[3]);
+                const double cn = std::sqrt((double)sp[0] * sp[0] + (double)sp[1] * sp[1] + (double)sp[2] * sp[2]);
+                const double K = 32.0 * eps;
+                grow_near[k] = std::sqrt(r * r + K * (ob_near + cn) * (ob_near + cn)) + walk;
+                grow_far[k] = std::sqrt(r * r + K * (ob_far + cn) * (ob_far + cn)) + walk;
+                rmax_near = std::max(rmax_near, grow_near[k]), rmax_far = std::max(rmax_far, grow_far[k]);
             }
-            grid_cells.resize(lists.size() * (grid_wide ? 2 : 1));
-            for (size_t c = 0; c < lists.size() && ok; ++c) {
-                const size_t n_near = lists[c].size(), n_all = n_near + extra[c].size();
-                if (n_all > max_per_cell || grid_items.size() + n_all >= max_items) ok = false;  // a clump: keep the cluster search
-                if (grid_wide)
-                    grid_cells[2 * c] = (uint32_t)grid_items.size(), grid_cells[2 * c + 1] = ((uint32_t)n_near << 8) | (uint32_t)n_all;
-                else
-                    grid_cells[c] = ((uint32_t)grid_items.size() << 12) | ((uint32_t)n_near << 6) | (uint32_t)n_all;
-                grid_items.insert(grid_items.end(), lists[c].begin(), lists[c].end());
-                grid_items.insert(grid_items.end(), extra[c].begin(), extra[c].end());
+            for (int a = 0; a < 3; ++a) {  // (empty without spheres: slo = +huge, shi = -huge)
+                blo[a] = slo[a] - rmax_far, bhi[a] = shi[a] + rmax_far;
+                nlo[a] = slo[a] - rmax_near, nhi[a] = shi[a] + rmax_near;
+            }
+            for (size_t k = 0; k < others.size(); ++k) {
+                if (!listed[k]) continue;
+                const rt_prim &p = s.prims[others[k]];
+                double corner2 = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    const double m = std::max(std::fabs(obox[k].lo[a]), std::fabs(obox[k].hi[a]));
+                    corner2 += m * m;
+                }
+                const double reach = ob_far + std::sqrt(corner2);
+                const double g = 64.0 * eps * reach + walk;
+                OBox b = obox[k];
+                if (p.type == RT_PRIM_CYLINDER) {
+                    const double R = std::fabs((double)p.f[0]);
+                    b = cyl_box(p, std::sqrt(R * R + 64.0 * eps * reach * reach), 64.0 * eps * reach);
+                }
+                for (int a = 0; a < 3; ++a) {
+                    b.lo[a] -= g, b.hi[a] += g;
+                    blo[a] = std::min(blo[a], b.lo[a]), bhi[a] = std::max(bhi[a], b.hi[a]);
+                    nlo[a] = std::min(nlo[a], b.lo[a]), nhi[a] = std::max(nhi[a], b.hi[a]);
+                }
+                listed_box[k] = b;
+            }
+            long long total = 1;
+            for (int a = 0; a < 3; ++a) {
+                const double span = bhi[a] - blo[a];
+                grid_n[a] = spread[a] ? (int)std::min(max_dim, std::max(1.0, std::ceil(span / cell))) : 1;
+                grid_min[a] = (float)blo[a];
+                grid_size[a] = (float)(span / grid_n[a]);
+                total *= grid_n[a];
+            }
+            if (total <= max_cells) break;
+            cell *= 1.3;
+        }
+        // near-tier lanes clip their rays to the bounds of the near-tier boxes: the far tier's, this much further in
+        double shrink = 1e300;
+        for (int a = 0; a < 3; ++a) shrink = std::min(shrink, std::min(nlo[a] - blo[a], bhi[a] - nhi[a]));
+        grid_shrink = (float)(std::max(0.0, shrink) * (1.0 - 1e-6));
+        const int nx = grid_n[0], ny = grid_n[1], nz = grid_n[2];
+        std::vector<std::vector<uint32_t>> lists((size_t)nx * ny * nz), extra((size_t)nx * ny * nz), olist((size_t)nx * ny * nz);
+        auto cell_of = [&](int a, double x) {
+            const int i = (int)std::floor((x - (double)grid_min[a]) / (double)grid_size[a]);
+            return std::min(std::max(i, 0), grid_n[a] - 1);
+        };
+        for (size_t k = 0; k < rest.size(); ++k) {
+            // the slot of this sphere: clusters of csize behind the prefix, one padding slot per cluster
+            const int slot = np_slots + (int)(k / csize) * cstride + (int)(k % csize);
+            int c0[3], c1[3], n0[3], n1[3];
+            for (int a = 0; a < 3; ++a) {
+                const double c = (double)s.prims[rest[k]].f[a];
+                c0[a] = cell_of(a, c - grow_far[k]), c1[a] = cell_of(a, c + grow_far[k]);
+                n0[a] = cell_of(a, c - grow_near[k]), n1[a] = cell_of(a, c + grow_near[k]);
+            }
+            for (int iz = c0[2]; iz <= c1[2]; ++iz)
+                for (int iy = c0[1]; iy <= c1[1]; ++iy)
+                    for (int ix = c0[0]; ix <= c1[0]; ++ix) {
+                        const bool near = ix >= n0[0] && ix <= n1[0] && iy >= n0[1] && iy <= n1[1] && iz >= n0[2] && iz <= n1[2];
+                        (near ? lists : extra)[((size_t)iz * ny + iy) * nx + ix].push_back((uint32_t)slot);
+                    }
+        }
+        // the other primitives; one that would be listed in more than 4096 cells is tested for every query instead
+        std::vector<char> too_wide(others.size(), 0);
+        for (size_t k = 0; k < others.size(); ++k) {
+            if (!listed[k]) continue;
+            int c0[3], c1[3];
+            long long cells = 1;
+            for (int a = 0; a < 3; ++a) {
+                c0[a] = cell_of(a, listed_box[k].lo[a]), c1[a] = cell_of(a, listed_box[k].hi[a]);
+                cells *= c1[a] - c0[a] + 1;
+            }
+            if (cells > 4096) {
+                too_wide[k] = 1;
+                continue;
+            }
+            for (int iz = c0[2]; iz <= c1[2]; ++iz)
+                for (int iy = c0[1]; iy <= c1[1]; ++iy)
+                    for (int ix = c0[0]; ix <= c1[0]; ++ix) olist[((size_t)iz * ny + iy) * nx + ix].push_back((uint32_t)gid_of[others[k]]);
+        }
+        bool retry = false;
+        for (size_t k = 0; k < others.size(); ++k)
+            if (too_wide[k]) forced[others[k]] = 1, retry = true;
+        if (retry) return false;
+        grid_cells.resize(lists.size() * (grid_wide ? 2 : 1));
+        overflow = false;
+        for (size_t cidx = 0; cidx < lists.size(); ++cidx) {
+            const size_t n_near = lists[cidx].size(), n_all = n_near + extra[cidx].size(), n_other = olist[cidx].size();
+            if (n_all > max_per_cell || n_other > max_other || grid_items.size() + n_all + n_other >= max_items) {
+                overflow = true;
+                if (grid_wide) {  // a clump even for the wide tables: its members are tested for every query from now on
+                    for (uint32_t slot : lists[cidx]) forced[slots[slot]] = 1;
+                    for (uint32_t slot : extra[cidx]) forced[slots[slot]] = 1;
+                    for (uint32_t g : olist[cidx]) {
+                        const int k = (int)g - ns_slots;  // position in the reordered tables: rects, cylinders, triangles
+                        forced[k < L.nr ? rec[k] : (k < L.nr + L.nc ? cyl[k - L.nr] : tri[k - L.nr - L.nc])] = 1;
+                    }
+                }
+                continue;
+            }
+            if (grid_wide)
+                grid_cells[2 * cidx] = (uint32_t)grid_items.size(),
+                                 grid_cells[2 * cidx + 1] = (uint32_t)n_near | ((uint32_t)n_all << 10) | ((uint32_t)n_other << 20);
+            else
+                grid_cells[cidx] = ((uint32_t)grid_items.size() << 12) | ((uint32_t)n_near << 6) | (uint32_t)n_all;
+            grid_items.insert(grid_items.end(), lists[cidx].begin(), lists[cidx].end());
+            grid_items.insert(grid_items.end(), extra[cidx].begin(), extra[cidx].end());
+            grid_items.insert(grid_items.end(), olist[cidx].begin(), olist[cidx].end());
+        }
+        if (overflow && grid_wide) return false;
+        // compact tables must also leave the kernel its full occupancy: otherwise the wide ones, read from global memory
+        if (!grid_wide) {
+            const size_t hot = (size_t)(off + 4 + ((int)grid_cells.size() + 3) / 4 + ((int)grid_items.size() + 1 + 7) / 8) * 16;
+            if (overflow || hot > (size_t)knob("RTMI_GLOBAL_TABLE_BYTES", (double)kLdsTableBytes)) {
+                grid_wide = true;
+                continue;  // once more, in the wide format
             }
         }
-        if (!ok) grid_cells.clear(), grid_items.clear(), grid_n[0] = grid_n[1] = grid_n[2] = 0;
+        break;
     }
+    if (n_listed == 0) grid_cells.clear(), grid_items.clear(), grid_n[0] = grid_n[1] = grid_n[2] = 0;
     L.grid_cells = (int)(grid_cells.size() / (grid_wide ? 2 : 1));
-    L.grid_wide = (!grid_cells.empty() && grid_wide) ? 1 : 0;
+    L.grid_wide = grid_wide ? 1 : 0;
     L.grid_sheet = (!grid_cells.empty() && grid_n[1] == 1 && !grid_wide) ? 1 : 0;
     L.off_grid = off;  // 4 records {min.xyz, ob_near^2} {1/size.xyz, ob_far^2} {size.xyz, shrink} {nx, ny, nz, -}, then cells, then items
     off += 4;
@@ -344,14 +540,14 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     off += ((int)grid_cells.size() + 3) / 4;
     L.off_grid_items = off;
     off += grid_wide ? ((int)grid_items.size() + 1 + 3) / 4 : ((int)grid_items.size() + 1 + 7) / 8;  // (+ 1: the pair test reads one entry past a list)
-    L.hot_vec4_grid = off;  // what the grid-walk kernel stages into LDS
-    // the boxes of the cluster searches (the fallback for scenes without a grid, and ablations) lie behind the grid tables,
-    // so that the grid walk does not stage them (RTIOW: 2.5 KB of 15.2 KB)
+    L.hot_vec4_grid = off;  // what the grid-walk kernels stage into LDS
+    // the boxes of the cluster searches (ablation builds) lie behind the grid tables, so that the grid walk does not stage
+    // them (RTIOW: 2.5 KB of 15.2 KB)
     L.off_box = off;
     off += 2 * n_clusters;
     L.off_wbox = off;
     off += 2 * n_windows;
-    L.off_gbox = off;  // outer boxes: the box-hierarchy variants read them
+    L.off_gbox = off;  // outer boxes: the box-hierarchy variant reads them
     off += 2 * n_groups;
     L.hot_vec4 = off;  // what the box-hierarchy and flat-scan variants stage into LDS
     L.rt_axes = axes;
@@ -404,58 +600,45 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
         cd[1] = bits(p.material);
         cd[2] = bits(pi);
     }
-    // Cluster boxes.  Skipping a cluster must never change the result of the fp32 sphere test, whose
-    // rounding error grows with the distance |oc| from the ray origin to the sphere: with unit
-    // roundoff e = 2^-24, |disc_fp32 - disc| <= 15 e a |oc|^2, so a ray the test can accept passes
-    // within r + sqrt(15 e)|oc| ~ r + 1e-3 |oc| of the centre, and its fp32 root lies within the same
-    // distance of that approach point: the hit point is inside the sphere's box grown by 2e-3 |oc|.
-    // |oc| <= sqrt(3) (max|o_i| + extent), so the KERNEL grows every box per lane by
+    // Boxes tested per lane with a margin (the cluster boxes of the ablation searches; the boxes of the cylinders and
+    // triangles that are tested for every query).  Skipping a box must never change the result of the fp32 test behind
+    // it, whose rounding error grows with the distance |oc| from the ray origin: with unit roundoff e = 2^-24,
+    // |disc_fp32 - disc| <= 15 e a |oc|^2, so a ray the sphere test can accept passes within r + sqrt(15 e)|oc| ~ r + 1e-3 |oc|
+    // of the centre, and its fp32 root lies within the same distance of that approach point: the hit point is inside the
+    // sphere's box grown by 2e-3 |oc|.  |oc| <= sqrt(3) (max|o_i| + extent), so the KERNEL grows every such box per lane by
     //     m = 4e-3 (max|o_i| + extent + 1)
-    // (two shifted ray origins per query, no extra work per box); a ray that leaked 2000 units
-    // inside the ground sphere thereby visits everything, exactly like the noise it would hit.
-    // The stored boxes only carry a 1e-5-relative pad for their own rounding.
-    float extent = 0.0f;  // max |coordinate| reached by a clustered sphere
+    // (two shifted ray origins per query, no extra work per box); a ray that leaked 2000 units inside the ground sphere
+    // thereby visits everything, exactly like the noise it would hit.  The stored boxes only carry a 1e-5-relative pad
+    // for their own rounding (the listed cylinders and triangles: their grid growth, which is larger).
+    float extent = 0.0f;  // max |coordinate| reached by a clustered sphere, a cylinder or a triangle
     for (int k = np_slots; k < (int)slots.size(); ++k) {
         if (slots[k] < 0) continue;
         const rt_prim &p = s.prims[slots[k]];
         for (int a = 0; a < 3; ++a) extent = std::max(extent, std::fabs(p.f[a]) + std::fabs(p.f[3]));
     }
-    // cylinders: world box of the open tube = union of the boxes of its two end circles
-    // (centre M (0,0,z), radius R, normal = the tube axis a: half-extent R sqrt(1 - a_i^2) on axis i)
-    std::vector<float> cyl_box((size_t)L.nc * 6);
+    auto other_index = [&](int prim) { return (size_t)oidx[prim]; };
     for (int k = 0; k < L.nc; ++k) {
-        const rt_prim &p = s.prims[cyl[k]];
-        const double R = std::fabs((double)p.f[0]);
-        double ax[3] = {p.m[2], p.m[6], p.m[10]};  // image of the object z axis
-        const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-        for (int a = 0; a < 3; ++a) {
-            const double ai = an > 0 ? ax[a] / an : 0.0;
-            const double half = R * std::sqrt(std::max(0.0, 1.0 - ai * ai));
-            const double c0 = p.m[a * 4 + 2] * (double)p.f[1] + p.m[a * 4 + 3];
-            const double c1 = p.m[a * 4 + 2] * (double)p.f[2] + p.m[a * 4 + 3];
-            const double lo = std::min(c0, c1) - half, hi = std::max(c0, c1) + half;
-            cyl_box[k * 6 + a] = (float)lo, cyl_box[k * 6 + 3 + a] = (float)hi;
-            extent = std::max(extent, (float)std::max(std::fabs(lo), std::fabs(hi)));
-        }
+        const OBox &b = obox[other_index(cyl[k])];
+        for (int a = 0; a < 3; ++a) extent = std::max(extent, (float)std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
     }
     for (int k = 0; k < L.nt; ++k) {
         const rt_prim &p = s.prims[tri[k]];
-        for (int c = 0; c < 9; ++c) extent = std::max(extent, std::fabs(p.m[c]));
+        for (int cc = 0; cc < 9; ++cc) extent = std::max(extent, std::fabs(p.m[cc]));
     }
     L.cull_extent1 = extent + 1.0f;
     const float inflate = 1e-5f * (extent + 1.0f);
-    for (int k = 0; k < L.nt; ++k) {
-        const rt_prim &p = s.prims[tri[k]];
-        float *b = rec4(L.off_tbox + 2 * k);
+    auto store_box = [&](float *b, int prim) {
+        const size_t k = other_index(prim);
+        const bool grown = listed[k] && !grid_cells.empty();
+        const OBox &src = grown ? listed_box[k] : obox[k];
         for (int a = 0; a < 3; ++a) {
-            b[a] = std::min(p.m[a], std::min(p.m[3 + a], p.m[6 + a])) - inflate;
-            b[4 + a] = std::max(p.m[a], std::max(p.m[3 + a], p.m[6 + a])) + inflate;
+            // (rounded outwards: the grown box is a double-precision bound)
+            b[a] = std::nextafterf((float)src.lo[a], -INFINITY) - inflate;
+            b[4 + a] = std::nextafterf((float)src.hi[a], INFINITY) + inflate;
         }
-    }
-    for (int k = 0; k < L.nc; ++k) {
-        float *b = rec4(L.off_cbox + 2 * k);
-        for (int a = 0; a < 3; ++a) b[a] = cyl_box[k * 6 + a] - inflate, b[4 + a] = cyl_box[k * 6 + 3 + a] + inflate;
-    }
+    };
+    for (int k = 0; k < L.nt; ++k) store_box(rec4(L.off_tri_hot + RT_TRI_STRIDE * k + 3), tri[k]);
+    for (int k = 0; k < L.nc; ++k) store_box(rec4(L.off_cyl_hot + RT_CYL_STRIDE * k + 4), cyl[k]);
     for (int q = 0; q < n_clusters; ++q) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = 0; k < csize; ++k) {
@@ -557,7 +740,7 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     }
     for (int k = 0; k < L.nc; ++k) {
         const rt_prim &p = s.prims[cyl[k]];
-        float *h = rec4(L.off_cyl_hot + 4 * k);
+        float *h = rec4(L.off_cyl_hot + RT_CYL_STRIDE * k);
         memcpy(h, p.m_inv, 12 * sizeof(float));
         h[12] = p.f[0] * p.f[0], h[13] = p.f[1], h[14] = p.f[2];
         float *cd = rec4(L.off_cyl_cold + 4 * k);
@@ -567,10 +750,10 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     }
     for (int k = 0; k < L.nt; ++k) {
         const rt_prim &p = s.prims[tri[k]];
-        float *h = rec4(L.off_tri_hot + 3 * k);
-        for (int c = 0; c < 3; ++c) {
-            h[4 * c] = p.m[3 * c], h[4 * c + 1] = p.m[3 * c + 1], h[4 * c + 2] = p.m[3 * c + 2];
-            h[4 * c + 3] = p.m[9 + c];
+        float *h = rec4(L.off_tri_hot + RT_TRI_STRIDE * k);
+        for (int cc = 0; cc < 3; ++cc) {
+            h[4 * cc] = p.m[3 * cc], h[4 * cc + 1] = p.m[3 * cc + 1], h[4 * cc + 2] = p.m[3 * cc + 2];
+            h[4 * cc + 3] = p.m[9 + cc];
         }
         float *cd = rec4(L.off_tri_cold + 2 * k);
         cd[0] = bits(p.material), cd[1] = bits(tri[k]);
@@ -633,6 +816,16 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
     for (int k = 0; k < L.nr; ++k) rec4(L.off_rect_cold + k)[2] = kind_of(s.prims[rec[k]].material);
     for (int k = 0; k < L.nc; ++k) rec4(L.off_cyl_cold + 4 * k)[14] = kind_of(s.prims[cyl[k]].material);
     c.packed_version = s.version;
+    return true;
+}
+
+static void pack_scene(const Scene &s, DeviceSceneCache &c) {
+    // a cell's list that overflows even the wide tables (more than a thousand primitives through one cell: a clump) moves its
+    // members to the always-tested set and the tables are rebuilt: in the limit the scene is scanned, which is the reference's
+    // algorithm.  Every round removes at least one primitive from the lists, and real scenes need none.
+    std::vector<char> forced(s.prims.size(), 0);
+    for (size_t round = 0; round <= s.prims.size(); ++round)
+        if (pack_scene_once(s, c, forced)) return;
 }
 
 // ---- shard geometry ----------------------------------------------------------------
@@ -702,6 +895,8 @@ int rt_shard_scatter_rows(const rt_scene *s, const rt_opts *o, const float *loca
     return RT_OK;
 }
 
+int rt_has_ablations(void) { return has_ablations() ? 1 : 0; }
+
 int rt_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -752,10 +947,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // frame (r = 0.22) gives up three of sixteen, a 1/8 row shard (r = 1.8) all sixteen, of which 22
     // quarter chunks are cut into 4-sample items.  Short items cost little since stragglers no longer
     // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
-    static const int tail_mode = getenv("RTMI_TAIL_MODE") ? atoi(getenv("RTMI_TAIL_MODE")) : 1;  // tuning knob, read once: 0 = off
-    static const double tail_factor = getenv("RTMI_TAIL_FACTOR") ? atof(getenv("RTMI_TAIL_FACTOR")) : 12.0;  // measured at 7 waves/SIMD: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms, a 1/8 shard 33.7 / 33.4 / 32.0 / 32.2 ms
-    static const int tail_div = getenv("RTMI_TAIL_DIV") ? std::max(2, atoi(getenv("RTMI_TAIL_DIV"))) : 4;  // big : medium item length
-    static const int orphan_env = getenv("RTMI_ORPHAN_MAX") ? atoi(getenv("RTMI_ORPHAN_MAX")) : -1;
+    // (knob(): measurement knobs of the default build, constants in a product build)
+    static const int tail_mode = (int)knob("RTMI_TAIL_MODE", 1);  // 0 = one run of equal chunks
+    static const double tail_factor = knob("RTMI_TAIL_FACTOR", 12.0);  // measured at 7 waves/SIMD: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms, a 1/8 shard 33.7 / 33.4 / 32.0 / 32.2 ms
+    static const int tail_div = std::max(2, (int)knob("RTMI_TAIL_DIV", 4));  // big : medium item length
+    static const int orphan_env = (int)knob("RTMI_ORPHAN_MAX", -1);
     int n_big = sample_count / spp_chunk, n_med = 0, q_med = spp_chunk, q_small = spp_chunk;
     int num_chunks, orphan_max = 12;
     {
@@ -796,16 +992,17 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
 
     unsigned variant = o ? o->variant : 0;
     if (!variant_exists(variant)) {
-        set_error("unknown kernel variant %u", variant);
+        set_error("unknown kernel variant %u%s", variant, has_ablations() ? "" : " (this library was built without the measurement variants: make ABLATIONS=1)");
         return RT_ERR_ARG;
+    }
+    if (count && !has_ablations()) {
+        set_error("rt_render_hip_count: this library was built without the counting kernels (make ABLATIONS=1)");
+        return RT_ERR_LIMIT;
     }
     // triangles and image textures live in separate builds of the kernels (template argument EXT)
     bool ext = !s.images.empty();
     for (const rt_prim &p : s.prims) ext = ext || p.type == RT_PRIM_TRIANGLE;
-    if (ext && count) {
-        set_error("the counting kernel has no build with triangles / image textures");
-        return RT_ERR_LIMIT;
-    }
+    const bool force_ext = knob_set("RTMI_FORCE_EXT");  // measurement: the EXT builds on scenes that do not need them
     int device = o ? o->device : 0;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -845,18 +1042,23 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         ent = cache.entries.back().get();
         ent->device = device;
     }
-    struct Events {  // destroyed on every return path
-        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    // timing events: three per (host thread, device), created at the thread's first timed call there and kept
+    struct Events {
+        std::vector<std::array<hipEvent_t, 3>> per_device;
         ~Events() {
-            for (hipEvent_t ev : e)
-                if (ev) (void)hipEventDestroy(ev);
+            for (auto &t : per_device)
+                for (hipEvent_t ev : t)
+                    if (ev) (void)hipEventDestroy(ev);
         }
-    } events;
-    hipEvent_t &ev0 = events.e[0], &ev1 = events.e[1], &ev2 = events.e[2];
+    };
+    static thread_local Events events;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     if (stats) {
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
-        HIP_TRY(hipEventCreate(&ev2));
+        if ((int)events.per_device.size() <= device) events.per_device.resize((size_t)device + 1, {nullptr, nullptr, nullptr});
+        auto &t = events.per_device[(size_t)device];
+        for (hipEvent_t &ev : t)
+            if (!ev) HIP_TRY(hipEventCreate(&ev));
+        ev0 = t[0], ev1 = t[1], ev2 = t[2];
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     size_t image_bytes = cache.image.size() * sizeof(float);
@@ -891,82 +1093,64 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     P.tiles_x = (s.width + 7) / 8;
     P.bands = (sh.local_rows + 7) / 8;
 
-    // LDS per workgroup: the hot tables (unless the variant reads them from global memory: bit 3) + one
-    // tile accumulator per wave.  The default kernel keeps the tables in LDS while that still leaves room
-    // for the kernel's full occupancy (RT_WAVES_PER_SIMD workgroups per CU); larger scenes run the same
-    // algorithm over global memory (variant 40: 4000 spheres 6.7 vs 19 ms), which has no size limit.
-    const size_t acc_lds = 4 * 192 * sizeof(unsigned long long);  // one 64-pixel rgb accumulator per wave
-    // (each candidate search stages the part of the hot tables it reads)
-    auto hot_bytes_of = [&](unsigned v) {
+    // ---- which kernel.  LDS per workgroup: the hot tables (unless the variant reads them from global memory: bit 3) + one
+    // tile accumulator per wave.  The tables live in LDS while that leaves room for the kernel's full occupancy
+    // (RT_WAVES_PER_SIMD workgroups per CU); larger scenes run the same walk over global memory (4000 spheres 6.7 vs 19 ms),
+    // which has no size limit.  The packer has chosen the table format (device_scene.h): COMPACT for sphere-only scenes whose
+    // tables fit that LDS budget, WIDE for every other scene.
+    const size_t acc_lds = kAccLds;
+    auto hot_bytes_of = [&](unsigned v) {  // (each candidate search stages the part of the hot tables it reads)
         const int mode = variant_cull_mode(v);
-        return (size_t)((mode == 5 || mode == 6 || mode == 7) ? P.hot_vec4_grid : ((mode == 3 || mode == 4) ? P.hot_vec4_tables : P.hot_vec4)) * 16;
+        if (mode == 5 || mode == 6 || mode == 7) return (size_t)P.hot_vec4_grid * 16;
+        return (size_t)((mode == 3 ? P.hot_vec4_tables : P.hot_vec4) - (P.off_box - P.off_grid)) * 16;  // (without the grid tables)
     };
-    static const size_t global_threshold = getenv("RTMI_GLOBAL_TABLE_BYTES") ? (size_t)atoll(getenv("RTMI_GLOBAL_TABLE_BYTES"))
-                                                                             : (size_t)(160 * 1024 / RT_WAVES_PER_SIMD) - acc_lds;
-    // The default candidate search is the uniform grid (RTIOW 40 against 57 ms per 256 spp for the range tables; 4000
-    // random spheres in a volume 6.7 against 21 ms for the box hierarchy).  Scenes whose clustered spheres have no grid
-    // (65536 sphere slots or more, or a clump of more than 63 in one cell) keep round 2's choice: the range tables -- the
-    // clusters a ray segment's BOUNDING BOX touches, sharp where the spheres lie on a sheet or are few -- and the box
-    // hierarchy (bit 6) where they fill a volume.
-    // (variant 2 is variant 0 for a grid that is one cell high: a walk along x and z only; the counting kernel and the
-    //  builds with triangles / image textures only exist for the 3-D walk, whose cells and tests are the same)
-    static const bool no_sheet = getenv("RTMI_NO_SHEET") != nullptr;  // A/B knob
-    // (variant 44 is the grid walk over the WIDE tables of scenes with 65536 sphere slots or more: global memory only;
-    //  the counting kernel and the triangle / texture builds have no wide form: they take the cluster search there)
-    const bool wide_unusable = P.grid_wide && (count || ext);
-    if (wide_unusable) P.grid_cells = 0, P.grid_wide = 0;
-    if (P.grid_wide && (variant == 1 || variant == 2 || variant == 40)) {
-        set_error("kernel variant %u reads the 16-bit grid tables; this scene (65536 sphere slots or more) has the wide ones: use variant 0 or 44", variant);
+    static const size_t global_threshold = (size_t)knob("RTMI_GLOBAL_TABLE_BYTES", (double)kLdsTableBytes);
+    const bool sphere_only = P.nr + P.nc + P.nt == 0 && !ext;
+    auto pick = [&]() -> unsigned {  // what variant 0 stands for in this scene
+        if (!P.grid_wide) return P.grid_sheet ? 2u : 6u;
+        return hot_bytes_of(36) <= global_threshold ? 36u : 44u;
+    };
+    if (variant == 0) variant = pick();
+    // the counting kernels exist for the grid walks (3-D) and two ablation searches: anything else is counted by the kernel
+    // variant 0 would run (reported in stats->kernel_variant / cull_mode)
+    if (count && !variant_has_count(variant)) variant = (variant == 2) ? 6u : pick();
+    if (count && variant == 2) variant = 6;
+    const int mode = variant_cull_mode(variant);
+    if ((mode == 5 || mode == 6) && P.grid_wide) {
+        set_error("kernel variant %u reads the compact grid tables of a sphere-only scene that fits LDS; this scene has the wide ones "
+                  "(other primitives, textures, 65536 sphere slots or more, or tables beyond %zu bytes): use variant 0, 36 or 44",
+                  variant, global_threshold);
         return RT_ERR_LIMIT;
     }
-    if (variant == 44 && !P.grid_wide) {
-        set_error("kernel variant 44 walks the wide grid tables of scenes with 65536 sphere slots or more, which this scene does not have");
+    if (mode == 7 && !P.grid_wide) {
+        set_error("kernel variant %u walks the wide grid tables; this scene (spheres only, small enough for LDS) has the compact ones: "
+                  "use variant 0, 2 or 6", variant);
         return RT_ERR_LIMIT;
     }
-    if (variant == 2 && (count || ext)) variant = 0;
     if (variant == 2 && !P.grid_sheet) {
         set_error("kernel variant 2 walks a grid that is one cell high, which this scene does not have");
         return RT_ERR_LIMIT;
     }
-    if (variant == 0) {
-        if (P.grid_cells > 0 || P.ncl == 0) {
-            if (P.grid_wide) variant = 44;
-            else if (hot_bytes_of(0) > global_threshold) variant = 40;
-            else if (P.grid_sheet && !count && !ext && !no_sheet) variant = 2;
-        } else {
-            const int n_axes = (P.rt_axes & 1) + ((P.rt_axes >> 1) & 1) + ((P.rt_axes >> 2) & 1);
-            variant = (n_axes == 3 && P.ncl > 16 && !ext) ? 64 : 128;  // (no EXT build of the box hierarchy)
-            if (variant == 128 && hot_bytes_of(128) > global_threshold) variant = 136;
-        }
-    }
-    if (variant == 64 && hot_bytes_of(64) > global_threshold) variant = 104;
-    size_t hot_bytes = hot_bytes_of(variant);
-    if ((variant_cull_mode(variant) == 5 || variant_cull_mode(variant) == 6 || variant_cull_mode(variant) == 7) && P.grid_cells == 0 && P.ncl > 0) {
-        set_error("kernel variant %u walks the uniform grid, which this scene does not have (more than 65535 sphere slots, "
-                  "or more than 63 spheres in one cell)", variant);
-        return RT_ERR_LIMIT;
-    }
     if (ext && !variant_has_ext(variant)) {
-        set_error("kernel variant %u has no build with triangles / image textures (variants 0, 16, 40, 128 and 136 have)", variant);
+        set_error("kernel variant %u has no build with triangles / image textures (variants 0, 36, 44 and the linear scans 16 / 24 have)", variant);
         return RT_ERR_LIMIT;
     }
-    // (the work-balanced kernel keeps a work list per wave behind the accumulators: RT_WL_BYTES in render_kernel.hip)
-    const size_t wl_lds = variant_cull_mode(variant) == 4 ? (size_t)4 * (64 * 8 + 64 * 6 * 2 + 16) : 0;
-    if (variant_cull_mode(variant) == 4 && (P.nwin > 1 || s.prims.size() >= 65535 || P.ns >= 65535)) {
-        set_error("kernel variant %u (work-balanced cluster tests) handles one window of 64 clusters and fewer than 65535 objects",
-                  variant);
+    if (!sphere_only && (mode == 5 || mode == 6)) {  // (cannot happen: such scenes get wide tables)
+        set_error("kernel variant %u is built for sphere-only scenes", variant);
         return RT_ERR_LIMIT;
     }
-    const size_t lds_bytes = ((variant & 8u) ? 0 : hot_bytes) + acc_lds + wl_lds;
-    static const bool debug_layout = getenv("RTMI_DEBUG_LAYOUT") != nullptr;
-    if (debug_layout) {
+    if (force_ext && variant_has_ext(variant) && P.grid_wide) ext = true;
+    const size_t hot_bytes = hot_bytes_of(variant);
+    const size_t lds_bytes = ((variant & 8u) ? 0 : hot_bytes) + acc_lds;
+    if (knob_set("RTMI_DEBUG_LAYOUT")) {
         const float *g = cache.image.data() + (size_t)P.off_grid * 4;
         int gn[3];
         memcpy(gn, g + 12, sizeof gn);
-        fprintf(stderr, "variant %u: LDS %zu bytes per workgroup (tables %zu); %d prefix slots, %d clusters of %d; grid %d x %d x %d = %d cells, "
-                "cell %.3f x %.3f x %.3f, %d list entries (vec4 records: cells %d, lists %d)\n",
-                variant, lds_bytes, (variant & 8u) ? (size_t)0 : hot_bytes, P.np, P.ncl, P.cluster, gn[0], gn[1], gn[2], P.grid_cells,
-                g[8], g[9], g[10], (P.hot_vec4_grid - P.off_grid_items) * 8, P.off_grid_items - P.off_grid_cells, P.hot_vec4_grid - P.off_grid_items);
+        fprintf(stderr, "variant %u: LDS %zu bytes per workgroup (tables %zu); %d prefix slots, %d clusters of %d; always-tested others %d + %d + %d "
+                "of %d + %d + %d; %s grid %d x %d x %d = %d cells, cell %.3f x %.3f x %.3f (vec4 records: cells %d, lists %d)\n",
+                variant, lds_bytes, (variant & 8u) ? (size_t)0 : hot_bytes, P.np, P.ncl, P.cluster, P.nr_a, P.nc_a, P.nt_a, P.nr, P.nc, P.nt,
+                P.grid_wide ? "wide" : "compact", gn[0], gn[1], gn[2], P.grid_cells,
+                g[8], g[9], g[10], P.off_grid_items - P.off_grid_cells, P.hot_vec4_grid - P.off_grid_items);
     }
     if (lds_bytes > 160 * 1024) {
         set_error("kernel variant %u keeps the scene tables in LDS and this scene needs %zu bytes per workgroup "
@@ -996,7 +1180,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ent->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const unsigned long long resident = (unsigned long long)ent->num_cus * blocks_per_cu(variant, count, lds_bytes, P.cluster, ext);
+    const unsigned long long resident = (unsigned long long)ent->num_cus * blocks_per_cu(variant, count, lds_bytes, ext);
     const unsigned long long need_blocks = (items64 + 3) / 4;
     const unsigned long long grid64 = need_blocks < resident ? (need_blocks ? need_blocks : 1) : resident;
 
@@ -1045,14 +1229,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             ip.local_rows = P.local_rows;
             launch_item_params(d_queue, ip, stream);
         }
-        // nothing worth culling (no sphere clusters, a handful of cylinders): the plain scan is the
-        // same result without the per-query box set-up
-        unsigned launch_variant = variant;
-        if (!count && (variant & 16u) == 0 && P.ncl == 0 && P.nc < 4 && P.nt < 4 && variant_exists(variant | 16u) &&
-            (!ext || variant_has_ext(variant | 16u)))
-            launch_variant = variant | 16u;
         if (s.max_depth > 0) {
-            launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, launch_variant, ext);
+            if (!launch_render(P, ent->d_image, ent->d_acc, d_queue, d_cnt, lds_bytes, (unsigned)grid64, stream, variant, ext)) {
+                set_error("kernel variant %u has no %s build", variant, count ? "counting" : (ext ? "triangle / texture" : "such"));
+                return RT_ERR_LIMIT;
+            }
             ++launches;
         }
         if (d_out) {
@@ -1067,6 +1248,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     HIP_TRY(hipGetLastError());
 
     if (stats) {
+        stats->kernel_variant = (int32_t)variant;  // what variant 0 (or a counting call) resolved to
         HIP_TRY(hipEventRecord(ev2, stream));
         lock.unlock();
         HIP_TRY(hipEventSynchronize(ev2));
@@ -1099,8 +1281,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->wave_start_spread_us = (double)(h.t_start_max - h.t_start_min) * 0.01;
             stats->wave_end_spread_us = (double)(h.t_end_max - h.t_end_min) * 0.01;
             stats->wave_span_us = (double)(h.t_end_max - h.t_start_min) * 0.01;
-            static const bool debug_drain = getenv("RTMI_DEBUG_DRAIN") != nullptr;
-            if (debug_drain) {
+            if (knob_set("RTMI_DEBUG_DRAIN")) {
                 fprintf(stderr, "shader clock over the waves' lifetimes: %.0f MHz\n", h.life_ticks ? 100.0 * (double)h.life_cycles / (double)h.life_ticks : 0.0);
                 fprintf(stderr, "queue-empty seen over %.1f us; first exit %.1f us after the first queue-empty; drain histogram (50 us bins):",
                         (double)(h.t_qe_max - h.t_qe_min) * 0.01, (double)(h.t_end_min - h.t_qe_min) * 0.01);
@@ -1121,7 +1302,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             stats->wave_queries = h.wave_queries;
             stats->cull_prefix = P.np, stats->cull_clusters = P.ncl, stats->cull_groups = P.ngr;
             stats->cull_cluster_size = P.cluster;
-            stats->cull_mode = variant_cull_mode(variant), stats->cull_windows = P.nwin;
+            stats->cull_mode = variant_cull_mode(variant), stats->cull_windows = P.nwin;  // (of the kernel that ran)
             stats->grid_sheet = P.grid_sheet;
         }
     }
@@ -1163,6 +1344,12 @@ static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_s
     int prev = 0;
     HIP_TRY(hipGetDevice(&prev));
     if (prev != device) HIP_TRY(hipSetDevice(device));
+    struct Restore {  // the caller's device comes back on every return path
+        int prev, cur;
+        ~Restore() {
+            if (prev != cur) (void)hipSetDevice(prev);
+        }
+    } restore{prev, device};
     const size_t bytes = (size_t)sh.local_rows * sc->s.width * 3 * sizeof(float);
     // the device framebuffer of this (scene, device) is kept between calls (no hipMalloc / hipFree per frame)
     float *d_out = nullptr;
@@ -1196,7 +1383,6 @@ static int render_host_buffer(const rt_scene *sc, const rt_opts *o, float *rgb_s
             rc = RT_ERR_HIP;
         }
     }
-    if (prev != device) (void)hipSetDevice(prev);
     return rc;
 }
 

@@ -52,43 +52,6 @@
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 7
 #endif
-// the flat-scan ablation kernels (CULL == 0) keep two register sets of sphere records in flight
-// CULL == 4: work-list entries a lane contributes per pass, and the list's capacity per wave
-#define RT_WL_PER_LANE 6
-#define RT_WL_CAP (64 * RT_WL_PER_LANE)
-#define RT_WL_BYTES (4 * (64 * 8 + RT_WL_CAP * 2 + 16))
-// MEASUREMENT ONLY (wrong images; never defined by the Makefile): what a section costs is what the frame gains when it
-// is cut out -- RT_ABLATE=1 rejection loops accept their first candidate, 2 no pixel accumulation, 4 the sample
-// seeding skips Philox, 8 no shading of hits (every hit ends the path)
-#ifndef RT_ABLATE
-#define RT_ABLATE 0
-#endif
-#define RT_ABLATE_REJ(cond) ((RT_ABLATE & 1) ? false : (cond))
-#ifndef RT_WAVES_LINEAR
-#define RT_WAVES_LINEAR RT_WAVES_PER_SIMD
-#endif
-// 1: the candidates of the prefix records 1..3 of a group share one resolve block (render_kernel, RT_SPHERE_PARK)
-#ifndef RT_PREFIX_PARK
-#define RT_PREFIX_PARK 1
-#endif
-// 1: the grid walk tests two entries of a cell's list per pass
-#ifndef RT_WALK_PAIR
-#define RT_WALK_PAIR 1
-#endif
-// candidate predicate of a sphere test: a real root that is not behind the origin.  1: evaluated without short-circuit
-// (three compares, one branch) instead of as two nested branches -- measured 146.5 against 145.5 ms, so 0
-// per-iteration scratch variables start undefined (an empty asm) instead of zero: 1 = the hit record (37 fewer v_mov: 136.1 ->
-// 134.8 ms, HBM writes 1.15 -> 1.32 GB through three more spilled registers at the item switch), 2 = also the walk's, the
-// rejection loop's and the jitter's (134.6 ms, 1.65 GB: not worth it)
-#ifndef RT_UNDEF_INIT
-#define RT_UNDEF_INIT 1
-#endif
-#ifndef RT_PARK_UNDEF
-#define RT_PARK_UNDEF 1
-#endif
-#ifndef RT_ITEM_SCALARS
-#define RT_ITEM_SCALARS 1
-#endif
 // Wave priority (s_setprio) of the sections of an iteration.  Seven waves share a SIMD's issue port; a wave in the closest-hit
 // query is a chain of short dependent steps (LDS reads, compares, branches) that wants its slot the moment its data is there,
 // a wave in the seeding or in the rejection loop is a long run of independent vector instructions that can fill any gap.
@@ -115,20 +78,9 @@
 #define RT_PRIO_S 1  /* after the rejection loop: scatter step, camera ray, ray tail */
 #endif
 // 1: the rejection loop draws three values per attempt for every lane and selects the state to keep (no inner branch)
-#ifndef RT_REJ_SELECT
-#define RT_REJ_SELECT 1
-#endif
-#ifndef RT_KEY_BARRIER
-#define RT_KEY_BARRIER 1
-#endif
-#ifndef RT_CAND_FLAT
-#define RT_CAND_FLAT 0
-#endif
-#if RT_CAND_FLAT
-#define RT_CAND(disc, hb, cc) ((int)!((disc) < 0.0f) & (int)!((int)((hb) >= 0.0f) & (int)((cc) >= 0.0f)))
-#else
+// candidate predicate of a sphere test: a real root that is not behind the origin (as two nested branches: evaluated without
+// short-circuit -- three compares, one branch -- it measured 146.5 against 145.5 ms)
 #define RT_CAND(disc, hb, cc) (!((disc) < 0.0f) && !((hb) >= 0.0f && (cc) >= 0.0f))
-#endif
 
 namespace rtmi {
 
@@ -141,18 +93,12 @@ struct LaneRng {
 };
 
 __device__ __forceinline__ void rng_start(LaneRng &r, uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1) {
-#if defined(RT_ABLATE) && (RT_ABLATE & 4)
-    r.g.x = pixel * 2654435761u, r.g.y = sample * 40503u + 1u, r.g.z = k0 ^ pixel, r.g.w = k1 + sample + 7u;
-#else
     // The key schedule (k + r W for the ten rounds) is wave-uniform and loop-invariant, so the compiler computes the twenty
     // words once per launch -- and then, out of scalar registers, keeps them in the lanes of a spill VGPR and fetches
     // them with v_readlane (plus hazard nops) in every seeding.  Behind this barrier the key is a fresh scalar of the
     // iteration, and the schedule is two s_add per round.
-#if RT_KEY_BARRIER
     asm volatile("" : "+s"(k0), "+s"(k1));
-#endif
     r.g = xor128_seed(pixel, sample, k0, k1);
-#endif
 }
 
 template <bool COUNT>
@@ -180,11 +126,7 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 // 0 and inf: 17 instructions.  The arguments of this kernel (discriminants, squared lengths) are ordinary numbers, so the
 // wrapping only runs -- through sqrtf() itself -- when some lane of the wave really holds such an argument: 11 instructions
 // otherwise.  The kernel takes ~10 square roots per iteration of its main loop.
-#ifndef RT_FAST_SQRT
-#define RT_FAST_SQRT 1
-#endif
 __device__ __forceinline__ float rt_sqrtf(float x) {
-#if RT_FAST_SQRT
     // [2^-96, inf): one unsigned compare on the bit pattern (negative numbers and NaN fall outside as well)
     if (__builtin_expect((uint32_t)(__float_as_uint(x) - 0x0f800000u) >= (0x7f800000u - 0x0f800000u), 0)) return sqrtf(x);
     const float s = __builtin_amdgcn_sqrtf(x);
@@ -193,9 +135,6 @@ __device__ __forceinline__ float rt_sqrtf(float x) {
     float r = r_dn <= 0.0f ? s_dn : s;
     r = r_up > 0.0f ? s_up : r;
     return r;
-#else
-    return sqrtf(x);
-#endif
 }
 
 // number of set bits of a lane mask as a 32-bit SCALAR (popcll's result is compared as a 64-bit value, for which the
@@ -261,56 +200,46 @@ __device__ __forceinline__ unsigned long long radiance_to_fixed(float v) {
 
 // ---------------------------------------------------------------- kernel
 // POOL:     idle lanes take the next (pixel, sample) item of the wave's tile (default)
-//           / false: a lane only renders samples of its own pixel
-// PREFETCH: sphere records are read from LDS one batch of four ahead (default)
-//           / false: one record per iteration, waited for in place
+//           / false: a lane only renders samples of its own pixel (ablation: the north_star's literal lane-per-pixel shape)
 // SCALAR:   nothing is staged in LDS: every table is read from global memory -- wave-uniform reads through
 //           the scalar cache (SGPR operands), per-lane reads through the vector L1/L2.  The mode for scenes
-//           whose tables would crowd out occupancy or not fit the 160 KB at all (and an ablation).  Was:
-//           the sphere table is read with wave-uniform loads from global memory (scalar
-//           cache -> SGPR operands) instead of LDS broadcast reads (experiment)
-// CULL:     after the always-tested big spheres, clusters of 8 spheres are visited only if some
-//           lane's ray passes the cluster's (inflated) bounding box: slab test of aabb.hpp:15-29
-//           + __any.  Conservative, so results are unchanged; fewer tests are executed.
-//           3 (default): every lane looks the CANDIDATE clusters of its ray segment up in the range tables (the
-//           segment's bounding box against precomputed per-axis cluster masks: three LDS reads instead of a
-//           box loop), keeps the candidates whose box its ray really reaches (the slab test above, per lane)
-//           and then walks its own list of clusters (per-lane LDS addresses), so a wave spends max-over-lanes
-//           instead of union-over-lanes cluster visits; 2: the same per-lane lists found through a two-level
-//           box hierarchy that every lane tests in full (round 1's default); 1: the whole wave visits every
-//           cluster some lane voted for; 0: no culling
-// CSIZE:    spheres per cluster (8 or 16: the packer picks per scene, RenderParams::cluster); a cluster occupies
-//           CSIZE + 1 slots (the last one never hit), which keeps the per-lane reads of different clusters on
-//           different LDS banks
+//           whose tables would crowd out occupancy or not fit the 160 KB at all.
+// CULL:     the candidate search of the closest-hit query.  Every search is conservative with respect to the fp32 error of
+//           the primitive tests, so the closest hit -- and the framebuffer -- equal the reference's linear scan bit for bit.
+//           5  uniform grid over the clustered spheres, COMPACT tables (16-bit list entries, one word per cell): sphere-only
+//              scenes whose tables fit LDS beside full occupancy.  Every lane walks the cells its ray crosses front to back.
+//           6  the same for a grid one cell high (a sheet of spheres on the ground: RTIOW): the walk has no y axis
+//           7  the same walk over the WIDE tables (32-bit list entries, two words per cell, up to 1023 cells per axis): every
+//              other scene.  Its cells also list the rectangles, cylinders and triangles (taichi-version/bvh.py:109-199
+//              indexes every hittable): a lane tests what its cells list; only the oversized primitives (the RTIOW ground,
+//              a room's walls) are tested for every query
+//           ablations (RTMI_ABLATIONS builds): 3 range tables, 2 two-level box hierarchy per lane (round 1's default), 1 wave
+//           votes per cluster box (aabb.hpp:15-29 + __any), 0 no culling: the reference's linear hittable_list scan
 // EXT:      the Taichi renderer's extras -- triangles (taichi-version/hittable.py:38-71) and image textures read at the
 //           hit record's (u, v) (material.py:137-144).  Only the builds for scenes that use them carry the code: it
 //           costs the kernel its register budget (86 spilled VGPRs instead of 23) whether a scene uses it or not.
-// SPH:      the scene holds spheres only (RTIOW, the 3-sphere scene, sample_scene.json): no rectangle / cylinder / triangle
-//           loops, no dispatch on the winner's type -- and, what pays, a dozen fewer launch values and loop-invariant masks
-//           competing for scalar registers (the surplus of those lives in the lanes of a spill VGPR: one v_readlane per use).
-//           Built for the default kernel (variants 0 and 2); chosen by launch_render.
-template <bool COUNT, bool POOL, bool PREFETCH, bool SCALAR, int CULL, int CSIZE, bool EXT = false, bool SPH = false>
-__global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SIMD)) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
+// SPH:      the scene holds spheres only (RTIOW, the 3-sphere scene): no rectangle / cylinder / triangle code, no dispatch
+//           on the winner's type -- and, what pays, a dozen fewer launch values and loop-invariant masks competing for scalar
+//           registers (the surplus of those lives in the lanes of a spill VGPR: one v_readlane per use).  The compact-table
+//           kernels (CULL 5, 6) are built this way only.
+template <bool COUNT, bool POOL, bool SCALAR, int CULL, bool EXT, bool SPH>
+__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const RenderParams P, const float4 *__restrict__ image,
                                                      unsigned long long *__restrict__ acc,
                                                      unsigned int *__restrict__ queue,
                                                      DevCounters *__restrict__ counters) {
     extern __shared__ float4 lds[];
-    // stage the hot tables (hittable_list contents) into LDS
-    // CULL == 6 is CULL == 5 for a grid that is one cell high (a sheet of spheres on the ground: RTIOW): the walk has no y axis
-    // CULL == 7 is CULL == 5 over the WIDE grid tables of scenes with 65536 sphere slots or more (32-bit list entries, two
-    // words per cell, 10 bits of steps per axis): global memory only (SCALAR)
     constexpr bool GRID = CULL == 5 || CULL == 6 || CULL == 7, SHEET = CULL == 6, WIDE = CULL == 7;
-    static_assert(!WIDE || SCALAR, "the wide grid tables are read from global memory");
-    const int staged = SCALAR ? 0 : (GRID ? P.hot_vec4_grid : ((CULL == 3 || CULL == 4) ? P.hot_vec4_tables : P.hot_vec4));
-    for (int i = threadIdx.x; i < staged; i += 256) lds[i] = image[i];
+    constexpr int CSIZE = RT_CLUSTER;
+    static_assert(!(CULL == 5 || CULL == 6) || SPH, "the compact grid tables list spheres only");
+    static_assert(!(SPH && EXT), "image textures and triangles come with the general builds");
+    // stage the hot tables (hittable_list contents) into LDS: each candidate search stages the part it reads
+    // (the cluster searches leave the grid tables, which lie in front of their boxes, out: `gap` records)
+    const int gap = (SCALAR || GRID) ? 0 : P.off_box - P.off_grid;
+    const int staged = SCALAR ? 0 : (GRID ? P.hot_vec4_grid : (CULL == 3 ? P.hot_vec4_tables : P.hot_vec4) - gap);
+    for (int i = threadIdx.x; i < staged; i += 256) lds[i] = image[i < P.off_grid ? i : i + gap];
     // per-wave tile accumulator of the current work item: 64 pixels x rgb, 64-bit fixed point
     unsigned long long *tile_acc = reinterpret_cast<unsigned long long *>(lds + staged);
     for (int i = threadIdx.x; i < 4 * 64 * 3; i += 256) tile_acc[i] = 0ull;
-    // CULL == 4: per-wave work list of (ray, cluster) items behind the accumulators: 64 result keys, RT_WL_CAP entries
-    // and the entry counter per wave
-    unsigned long long *wl_key = tile_acc + 4 * 192;
-    unsigned short *wl_ent = reinterpret_cast<unsigned short *>(wl_key + 4 * 64);
-    unsigned int *wl_cnt = reinterpret_cast<unsigned int *>(wl_ent + 4 * RT_WL_CAP);
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (wave: in a scalar register)
@@ -429,7 +358,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
     //       metal hit (three draws per attempt) and random_in_unit_disk for the lens sample of a new path (two)
     //   (6) the scatter step (lambertian / metal / dielectric) | the camera ray, then what both share: |d|^2, 1 / |d|^2
     // The loops of (5) cost max-over-lanes attempts each; as two loops (one inside the refill, one inside the shading)
-    // they took 13 % of the frame (measured by cutting them out, RT_ABLATE=1).
+    // they took 13 % of the frame (measured by cutting them out).
     // CULL == 5: ray parameter at which this lane's grid walk was cut short in the previous iteration (0: it was not);
     // the walk goes on from there in this one
     float t_res = 0.0f;
@@ -441,16 +370,13 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         // the winner's hit record, kept for the scatter step
         float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0, inv_len = 0;
         int mat = 0, kind = -1;  // kind >= 0: a scatter step is due in (6)
-#if RT_UNDEF_INIT
         // (only lanes with kind >= 0 read the record, and they have written it; an "undefined" value from an empty asm
         //  spares the eight v_mov ..., 0 per iteration that the zero initialisers above cost)
         asm volatile("" : "=v"(px), "=v"(py), "=v"(pz), "=v"(nx), "=v"(ny), "=v"(nz), "=v"(inv_len), "=v"(mat));
-#endif
         bool front = false;
         float tex_r = 0, tex_g = 0, tex_b = 0;  // the texel of an image texture at the hit's (u, v)
         if (__any(active)) {
-        {   // (declarations for every lane; the work below is guarded by `active` part by part, because the
-            //  work-balanced cluster tests of CULL == 4 need the lanes WITHOUT a live path as well)
+        {
             // ---- closest-hit query over the LDS-resident list (hittable_list::hit,
             // object.cuh:23-37).  Wave-uniform trip counts; `best_id` is the grouped id.
             float best_t = INFINITY;
@@ -531,31 +457,22 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
             for (int i = 0; i < P.np; i += 4) {
                 const float4 s0 = sph[i], s1 = sph[i + 1], s2 = sph[i + 2], s3 = sph[i + 3];
                 RT_SPHERE_TEST(s0, i)
-#if RT_PREFIX_PARK
                 int p_idx = -1;
                 float p_hb = 0.0f, p_disc = 0.0f;
-#if RT_PARK_UNDEF
                 asm volatile("" : "=v"(p_hb), "=v"(p_disc));  // (read only where p_idx >= 0, which comes with their values)
-#endif
                 RT_SPHERE_PARK(s1, i + 1)
                 RT_SPHERE_PARK(s2, i + 2)
                 RT_SPHERE_PARK(s3, i + 3)
                 if (p_idx >= 0) resolve(p_idx, p_hb, p_disc);
-#else
-                RT_SPHERE_TEST(s1, i + 1)
-                RT_SPHERE_TEST(s2, i + 2)
-                RT_SPHERE_TEST(s3, i + 3)
-#endif
             }
             if (!CULL) {
-                // flat scan (the reference's hittable_list loop) of every cluster's CSIZE records (clusters are
-                // CSIZE + 1 slots apart, see the packer)
-                if (PREFETCH) {
-                    // 16 records per iteration (one 16-cluster or two 8-clusters, the never-hit slot between them
-                    // skipped), in two register sets of four fetched half a step ahead of their use; the table ends
-                    // with all-padding clusters, so the last read-ahead stays inside it
-                    constexpr int kStep = CSIZE == 8 ? 18 : 17;
-#define RT_OFF(k) ((k) + ((CSIZE == 8 && (k) >= 8) ? 1 : 0))
+                // flat scan (the reference's hittable_list loop) of every cluster's 8 records (clusters are 9 slots apart,
+                // see the packer): 16 records per iteration -- two clusters, the never-hit slot between them skipped -- in two
+                // register sets of four fetched half a step ahead of their use; the table ends with all-padding clusters, so
+                // the last read-ahead stays inside it
+                {
+                    constexpr int kStep = 2 * (CSIZE + 1);
+#define RT_OFF(k) ((k) + ((k) >= CSIZE ? 1 : 0))
                     const int iters = (P.ncl * CSIZE + 15) / 16;
                     int base = P.np;
                     float4 a0 = sph[base], a1 = sph[base + 1], a2 = sph[base + 2], a3 = sph[base + 3];
@@ -578,15 +495,6 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         base += kStep;
                     }
 #undef RT_OFF
-                } else {
-                    for (int q = 0; q < P.ncl; ++q) {
-                        const int base = P.np + (CSIZE + 1) * q;
-#pragma unroll 4
-                        for (int h = 0; h < CSIZE; ++h) {
-                            const float4 s = sph[base + h];
-                            RT_SPHERE_TEST(s, base + h)
-                        }
-                    }
                 }
             }
             }
@@ -620,8 +528,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 b.nxp = -(ox - b.marg) * b.idx, b.nyp = -(oy - b.marg) * b.idy, b.nzp = -(oz - b.marg) * b.idz;
                 return b;
             };
-            const float4 *box = hot + P.off_box;
-            const float4 *gbox = hot + P.off_gbox;
+            const float4 *box = hot + (P.off_box - gap);
+            const float4 *gbox = hot + (P.off_gbox - gap);
             // best_t (1 + 1e-4), refreshed whenever spheres have been tested (a stale, larger value only
             // culls less)
             float blim = best_t * 1.0001f;
@@ -635,14 +543,125 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), blim), fmaxf(lz, uz));
                 return !(tn > tf);
             };
-            unsigned long long cand4 = 0ull;  // CULL == 4: this lane's candidate clusters (one window)
+            // ---- the other primitives' tests (one primitive, index uniform or per lane)
+            // axis-aligned rects: xy_rect/xz_rect/yz_rect::hit, object.cuh:105-192
+            auto test_rect = [&](int j) {
+                const float4 q0 = rect[2 * j], q1 = rect[2 * j + 1];
+                const int axis = __float_as_int(q1.y);  // 0: z = k, 1: y = k, 2: x = k
+                float ok, dk, oa, da, ob, db;
+                if (axis == 0) ok = oz, dk = dz, oa = ox, da = dx, ob = oy, db = dy;
+                else if (axis == 1) ok = oy, dk = dy, oa = ox, da = dx, ob = oz, db = dz;
+                else ok = ox, dk = dx, oa = oy, da = dy, ob = oz, db = dz;
+                const float t = (q1.x - ok) / dk;
+                if (!(t < kTMin || t > best_t)) {
+                    const float pa = fmaf(t, da, oa), pb = fmaf(t, db, ob);
+                    if (!(pa < q0.x || pa > q0.y || pb < q0.z || pb > q0.w)) {
+                        bool take = true;
+                        if (t == best_t && best_id >= 0)  // tie: the later list entry wins
+                            take = list_index_of(P, image, ns + j) > list_index_of(P, image, best_id);
+                        if (take) {
+                            best_t = t;
+                            best_id = ns + j;
+                        }
+                    }
+                }
+            };
+            // cylinders: cylinder::hit + quadratic, object.cuh:199-214, 233-290
+            auto test_cyl = [&](int k) {
+                const float4 r0 = cyl[RT_CYL_STRIDE * k], r1 = cyl[RT_CYL_STRIDE * k + 1], r2 = cyl[RT_CYL_STRIDE * k + 2], pr = cyl[RT_CYL_STRIDE * k + 3];
+                const float oox = fmaf(r0.x, ox, fmaf(r0.y, oy, fmaf(r0.z, oz, r0.w)));
+                const float ooy = fmaf(r1.x, ox, fmaf(r1.y, oy, fmaf(r1.z, oz, r1.w)));
+                const float ooz = fmaf(r2.x, ox, fmaf(r2.y, oy, fmaf(r2.z, oz, r2.w)));
+                const float odx = fmaf(r0.x, dx, fmaf(r0.y, dy, r0.z * dz));
+                const float ody = fmaf(r1.x, dx, fmaf(r1.y, dy, r1.z * dz));
+                const float odz = fmaf(r2.x, dx, fmaf(r2.y, dy, r2.z * dz));
+                const float qa = fmaf(odx, odx, ody * ody);
+                const float qb = 2.0f * fmaf(odx, oox, ody * ooy);
+                const float qc = fmaf(oox, oox, fmaf(ooy, ooy, -pr.x));
+                const float delta = fmaf(qb, qb, -((4.0f * qa) * qc));
+                if (!(delta < 0.0f)) {
+                    const float sq = rt_sqrtf(delta);
+                    float t0 = (-0.5f * (qb - sq)) / qa;
+                    float t1 = (-0.5f * (qb + sq)) / qa;
+                    if (t0 > t1) {
+                        const float tmp = t0;
+                        t0 = t1;
+                        t1 = tmp;
+                    }
+                    bool ok = !(t0 > best_t || t1 < kTMin);
+                    float t = t0;
+                    if (ok && t0 < kTMin) {
+                        t = t1;
+                        if (t > best_t) ok = false;
+                    }
+                    if (ok) {
+                        float opz = fmaf(t, odz, ooz);
+                        if (opz < pr.y || opz > pr.z) {
+                            if (t == t1) ok = false;
+                            else {
+                                t = t1;
+                                if (t > best_t || t < kTMin) ok = false;
+                                else {
+                                    opz = fmaf(t, odz, ooz);
+                                    if (opz < pr.y || opz > pr.z) ok = false;
+                                }
+                            }
+                        }
+                    }
+                    if (ok) {
+                        bool take = true;
+                        if (t == best_t && best_id >= 0)
+                            take = list_index_of(P, image, ns + nr + k) > list_index_of(P, image, best_id);
+                        if (take) {
+                            best_t = t;
+                            best_id = ns + nr + k;
+                        }
+                    }
+                }
+            };
+            // triangles: hit_triangle, taichi-version/hittable.py:38-71 -- the plane of the triangle (its unit normal
+            // turned towards the ray origin), then four same-side tests of the plane point
+            auto test_tri = [&](int k) {
+                const float4 r0 = tri[RT_TRI_STRIDE * k], r1 = tri[RT_TRI_STRIDE * k + 1], r2 = tri[RT_TRI_STRIDE * k + 2];
+                float rix, riy, riz, root;
+                if (tri_plane(r0, r1, r2, rix, riy, riz, root) && !(root < kTMin || root > best_t)) {
+                    const float e21x = r1.x - r0.x, e21y = r1.y - r0.y, e21z = r1.z - r0.z;
+                    const float e31x = r2.x - r0.x, e31y = r2.y - r0.y, e31z = r2.z - r0.z;
+                    const float e32x = r2.x - r1.x, e32y = r2.y - r1.y, e32z = r2.z - r1.z;
+                    const float a1x = rix - r0.x, a1y = riy - r0.y, a1z = riz - r0.z;
+                    const float a2x = rix - r1.x, a2y = riy - r1.y, a2z = riz - r1.z;
+                    float px_, py_, pz_, qx_, qy_, qz_;
+                    cross3(a1x, a1y, a1z, e21x, e21y, e21z, px_, py_, pz_);
+                    cross3(e31x, e31y, e31z, e21x, e21y, e21z, qx_, qy_, qz_);
+                    const float n1 = dot3(px_, py_, pz_, qx_, qy_, qz_);
+                    cross3(a2x, a2y, a2z, -e21x, -e21y, -e21z, px_, py_, pz_);
+                    cross3(e32x, e32y, e32z, -e21x, -e21y, -e21z, qx_, qy_, qz_);
+                    const float n2 = dot3(px_, py_, pz_, qx_, qy_, qz_);
+                    cross3(a1x, a1y, a1z, e31x, e31y, e31z, px_, py_, pz_);
+                    cross3(e21x, e21y, e21z, e31x, e31y, e31z, qx_, qy_, qz_);
+                    const float n3 = dot3(px_, py_, pz_, qx_, qy_, qz_);
+                    cross3(a2x, a2y, a2z, e32x, e32y, e32z, px_, py_, pz_);
+                    cross3(-e21x, -e21y, -e21z, e32x, e32y, e32z, qx_, qy_, qz_);
+                    const float n4 = dot3(px_, py_, pz_, qx_, qy_, qz_);
+                    if (n1 > 0.0f && n2 > 0.0f && n3 > 0.0f && n4 > 0.0f) {
+                        bool take = true;
+                        if (root == best_t && best_id >= 0)
+                            take = list_index_of(P, image, ns + nr + nc + k) > list_index_of(P, image, best_id);
+                        if (take) {
+                            best_t = root;
+                            best_id = ns + nr + nc + k;
+                        }
+                    }
+                }
+            };
+            bool far_scan = false;  // GRID: this lane's origin lies beyond the reach of the cells' lists: it scans what they list
             if (active) {
-            if (GRID) {
-                // ---- uniform grid, 3-D DDA per lane (the default).  The clustered spheres are listed in the cells
-                // their (error-grown, see the packer) boxes touch; a lane walks the cells its ray crosses in the order it
-                // crosses them and tests what they list, so the nearest hit ends the walk: a cell is only entered while
-                // its entry distance is within best_t (1 + 1e-4).  One loop for the whole wave, in which a lane either
-                // tests ONE sphere of its current cell or steps to its next cell.
+            if (GRID && P.grid_cells != 0) {  // (no cells: a scene small enough for every primitive to be tested per query)
+                // ---- uniform grid, 3-D DDA per lane (the default).  The clustered spheres -- and, in the wide tables, the
+                // rectangles, cylinders and triangles that are not oversized -- are listed in the cells their (error-grown, see
+                // the packer) boxes touch; a lane walks the cells its ray crosses in the order it crosses them and tests what
+                // they list, so the nearest hit ends the walk: a cell is only entered while its entry distance is within
+                // best_t (1 + 1e-4).
                 const float4 *gh = hot + P.off_grid;
                 const float4 g_min = gh[0], g_inv = gh[1], g_size = gh[2];
                 const int gnx = __float_as_int(gh[3].x), gny = __float_as_int(gh[3].y), gnz = __float_as_int(gh[3].z);
@@ -652,20 +671,25 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 // which tier of the cells' lists covers this lane's origin (the packer: |o| against ob_near, ob_far)
                 const float o2 = fmaf(ox, ox, fmaf(oy, oy, oz * oz));
                 const bool tier_far = o2 > g_min.w, beyond = o2 > g_inv.w;
-                const int cnt_shift = tier_far ? 0 : (WIDE ? 8 : 6);  // header: (first << 12) | (n_near << 6) | n_all; wide: {first, (n_near << 8) | n_all}
+                // cell header, compact: (first << 12) | (n_near << 6) | n_all;  wide: {first, n_near | n_all << 10 | n_other << 20}:
+                // the sphere entries [first, + n_near) serve near origins, [first, + n_all) far ones, and the n_other entries
+                // behind them are the cell's other primitives (grouped ids)
+                const int cnt_shift = tier_far ? (WIDE ? 10 : 0) : (WIDE ? 0 : 6);
                 constexpr int REM_BITS = WIDE ? 10 : 8;            // steps left per axis, packed in one register
-                constexpr uint32_t REM_MASK = (1u << REM_BITS) - 1u, CNT_MASK = WIDE ? 255u : 63u;
+                constexpr uint32_t REM_MASK = (1u << REM_BITS) - 1u, CNT_MASK = WIDE ? 1023u : 63u;
+                constexpr bool OTHERS = WIDE && !SPH;
                 const uint32_t *g_items32 = reinterpret_cast<const uint32_t *>(g_items);
+                int ko = 0, koend = 0;  // OTHERS: the entries of the cell's other primitives still to test
                 auto cell_list = [&](int cell, int &first, int &end) {  // a cell's list entries [first, end) of this lane's tier
                     if (WIDE) {
                         const uint2 h = reinterpret_cast<const uint2 *>(g_cells)[cell];
                         first = (int)h.x, end = first + (int)((h.y >> cnt_shift) & CNT_MASK);
+                        if (OTHERS) ko = (int)h.x + (int)((h.y >> 10) & CNT_MASK), koend = ko + (int)(h.y >> 20);
                     } else {
                         const uint32_t h = g_cells[cell];
                         first = (int)(h >> 12), end = first + (int)((h >> cnt_shift) & CNT_MASK);
                     }
                 };
-                bool far_scan = false;
                 // the grid's bounds (un-grown: the lists carry the growth); the near tier's lie g_size.w further in
                 const float shrink = tier_far ? 0.0f : g_size.w;
                 const float bx0 = g_min.x + shrink, by0 = g_min.y + shrink, bz0 = g_min.z + shrink;
@@ -679,12 +703,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 int ci = 0, k = 0, kend = 0;
                 uint32_t rem = 0;  // steps left before the ray leaves the grid: x | y << 8 | z << 16
                 float tmx = INFINITY, tmy = INFINITY, tmz = INFINITY, t_exit = 0.0f;
-#if RT_UNDEF_INIT > 1
-                asm volatile("" : "=v"(ci), "=v"(rem), "=v"(tmx), "=v"(tmy), "=v"(tmz), "=v"(t_exit));  // (read by live lanes only, which set them)
-#endif
-                if (P.grid_cells == 0) {
-                    // no clustered spheres, no grid (the host refuses this kernel if there are clustered spheres without one)
-                } else if (beyond) {
+                if (beyond) {
                     const float4 fmn = {bx0, by0, bz0, 0.0f}, fmx = {bx1, by1, bz1, 0.0f};
                     far_scan = slab_live(bp, fmn, fmx);
                 } else {
@@ -735,7 +754,6 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 while (__builtin_amdgcn_ballot_w64(live) != 0ull) {
                     while (__builtin_amdgcn_ballot_w64(k < kend) != 0ull) {
                         if (COUNT) c_clusters++;
-#if RT_WALK_PAIR
                         // two list entries per pass: both index reads, then both record reads, are in flight together, and a
                         // cell's list costs the wave ceil(n / 2) passes (each a dependent LDS round trip, exec-mask
                         // bookkeeping and a taken branch) instead of n.  A list of odd length reads the never-hit slot
@@ -749,27 +767,47 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                             const float4 S = sph[idx], T = sph[jdx];
                             int p_idx = -1;
                             float p_hb = 0.0f, p_disc = 0.0f;
-#if RT_PARK_UNDEF
                             asm volatile("" : "=v"(p_hb), "=v"(p_disc));
-#endif
                             RT_SPHERE_PARK(S, idx)
                             RT_SPHERE_PARK(T, jdx)
                             if (p_idx >= 0) resolve(p_idx, p_hb, p_disc);
                         }
-#else
-                        if (k < kend) {
-                            const int idx = WIDE ? (int)g_items32[k] : (int)g_items[k];
-                            ++k;
-                            const float4 S = sph[idx];
-                            if (COUNT) c_lane_clusters++;
-                            RT_SPHERE_TEST(S, idx)
-                        }
-#endif
                         // (the masks of the two conditions are combined as scalars, and the count is declared wave-uniform:
                         //  ballot(a && b) of two lane masks goes through a VGPR, and its popcount is compared as a vector)
                         if (RT_STEP_AT < 65 &&
                             mask_count(__builtin_amdgcn_ballot_w64(live) & ~__builtin_amdgcn_ballot_w64(k < kend)) >= RT_STEP_AT)
                             break;
+                    }
+                    // the cell's other primitives, one per lane and pass, for the lanes that are through with its spheres
+                    if (OTHERS) {
+                        while (__builtin_amdgcn_ballot_w64(live && !(k < kend) && ko < koend) != 0ull) {
+                            if (live && !(k < kend) && ko < koend) {
+                                const int id = (int)g_items32[ko];
+                                ++ko;
+                                if (COUNT) c_lane_clusters++;
+                                if (id < ns + nr) {
+                                    test_rect(id - ns);
+                                } else {
+                                    // behind the primitive's (host-grown) box: exact slab distances, as at the grid's bounds.  (The box
+                                    // lies behind the primitive's records, in the same lines of memory.  Reading all of them at
+                                    // once, so that the test's operands travel while the box is tested, costs 24 registers and
+                                    // lost: 20000 triangles 30.5 -> 31.7 ms, the DNA frame 7.05 -> 7.47 ms.)
+                                    const bool is_cyl = id < ns + nr + nc;
+                                    const int kk = is_cyl ? id - ns - nr : id - ns - nr - nc;
+                                    const float4 *bb = is_cyl ? cyl + RT_CYL_STRIDE * kk + 4 : tri + RT_TRI_STRIDE * kk + 3;
+                                    const float4 bmn = bb[0], bmx = bb[1];
+                                    const float lx = (bmn.x - ox) * bp.idx, ux = (bmx.x - ox) * bp.idx;
+                                    const float ly = (bmn.y - oy) * bp.idy, uy = (bmx.y - oy) * bp.idy;
+                                    const float lz = (bmn.z - oz) * bp.idz, uz = (bmx.z - oz) * bp.idz;
+                                    const float tn = fmaxf(fmaxf(fmaxf(fminf(lx, ux), fminf(ly, uy)), 0.0f), fminf(lz, uz));
+                                    const float tf = fminf(fminf(fminf(fmaxf(lx, ux), fmaxf(ly, uy)), best_t * 1.0001f), fmaxf(lz, uz));
+                                    if (!(tn > tf)) {
+                                        if (is_cyl) test_cyl(kk);
+                                        else if (EXT) test_tri(kk);
+                                    }
+                                }
+                            }
+                        }
                     }
                     if (COUNT) c_groups++;
                     // The tail: a wave's walk lasts as long as its slowest lane's (11 test and 4 step passes for 2.8 tests
@@ -780,13 +818,13 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const unsigned long long walking = __builtin_amdgcn_ballot_w64(live);
                     const bool cut = RT_WALK_TAIL > 0 && mask_count(walking) <= RT_WALK_TAIL &&
                                      mask_count(__builtin_amdgcn_ballot_w64(active) & ~walking) >= RT_WALK_WAITING;
-                    if (live && !(k < kend)) {
+                    if (live && !(k < kend) && !(OTHERS && ko < koend)) {
                         const float tnext = SHEET ? fminf(tmx, tmz) : fminf(fminf(tmx, tmy), tmz);
                         const bool xle = tmx == tnext, yle = !SHEET && !xle && tmy == tnext;
                         const int sh = xle ? 0 : (yle ? REM_BITS : 2 * REM_BITS);
                         if (tnext > fminf(t_exit, best_t * 1.0001f) || ((rem >> sh) & REM_MASK) == 0u) {
                             live = false;
-                        } else if (cut && tnext > t_from) {
+                        } else if (cut && tnext > t_from && !(best_t < tnext)) {  // (a hit inside the cell being left stays: the walk ends at the next boundary test)
                             live = false;
                             t_res = tnext;
                         } else {
@@ -814,13 +852,13 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     }
                 }
                 blim = best_t * 1.0001f;
-            } else if (CULL == 3 || CULL == 4) {
+            } else if (CULL == 3) {
                 // windows of 64 clusters: one mask bit per cluster
                 for (int w0 = 0; w0 < P.nwin; ++w0) {
                     // clip the ray to the window box (the union of its cluster boxes; same margin as every box test)
                     const BoxP bp = box_params();
                     const float idx = bp.idx, idy = bp.idy, idz = bp.idz, marg = bp.marg;
-                    const float4 *wb = hot + P.off_wbox + 2 * w0;
+                    const float4 *wb = hot + (P.off_wbox - gap) + 2 * w0;
                     const float4 wmn = wb[0], wmx = wb[1];
                     blim = best_t * 1.0001f;  // what the prefix and the previous windows found
                     const float lx = fmaf(wmn.x, idx, bp.nxm), ux = fmaf(wmx.x, idx, bp.nxp);
@@ -837,7 +875,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     // segment's box on every axis, so it is in the intersection of the three masks
                     unsigned long long cand = 0ull;
                     if (wlive) {
-                        const float4 *hd = hot + P.off_rtab + w0 * P.rt_stride;
+                        const float4 *hd = hot + (P.off_rtab - gap) + w0 * P.rt_stride;
                         const float4 gmn = hd[0], giw = hd[1];
                         const unsigned long long *tab = reinterpret_cast<const unsigned long long *>(hd + 2);
                         cand = ~0ull;
@@ -865,10 +903,6 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         const int left = P.ncl - w0 * 64;  // the last window may hold fewer than 64 clusters
                         if (left < 64) cand &= (1ull << left) - 1ull;
                         if (COUNT) c_lane_cands += (uint32_t)__popcll(cand);
-                    }
-                    if (CULL == 4) {  // the candidates are tested below, spread over all lanes of the wave
-                        cand4 = cand;
-                        continue;
                     }
                     // phase 2: keep the candidates whose own box the ray reaches (per-lane box reads)
                     unsigned long long mine = 0ull;
@@ -914,7 +948,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 for (int g0 = 0; g0 < P.ngr; g0 += 64 / RT_GROUP) {
                     // big scenes: one box around the whole window first (third level of the hierarchy)
                     if (P.nwin > 1) {
-                        const float4 *wb = hot + P.off_wbox + 2 * (g0 / (64 / RT_GROUP));
+                        const float4 *wb = hot + (P.off_wbox - gap) + 2 * (g0 / (64 / RT_GROUP));
                         if (__builtin_amdgcn_ballot_w64(slab_live(bp, wb[0], wb[1])) == 0ull) continue;
                         blim = best_t * 1.0001f;  // what the previous windows found tightens this one
                     }
@@ -991,240 +1025,39 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 }
             }
             }  // if (active): candidate search
-            if (CULL == 4) {
-                // ---- work-balanced cluster tests.  A ray needs 3 candidate clusters on average, the wave's slowest
-                // lane 8.6: walked lane by lane, a wave spends max-over-lanes rounds of 8 sphere tests with 2 of 3 slots
-                // idle.  Here every candidate (ray, cluster) pair of the wave becomes a work item in a per-wave list in
-                // LDS; item i is tested by lane i mod 64, which fetches the ray from its owner's registers
-                // (ds_bpermute), tests the cluster's 8 spheres and merges its closest hit into the owner's result slot
-                // with ONE 64-bit LDS atomic min on the key {t, 0xFFFF - list index, slot}: the smallest key is the
-                // closest hit and, among equal t, the later list entry (hittable_list::hit's tie rule).
-                unsigned long long *wkey = wl_key + wave * 64;
-                unsigned short *went = wl_ent + wave * RT_WL_CAP;
-                unsigned int *wcnt = wl_cnt + wave * 4;
-                wkey[lane] = ~0ull;
-                const float own_t = best_t;  // what the prefix found bounds every candidate root
-                while (__builtin_amdgcn_ballot_w64(cand4 != 0ull) != 0ull) {
-                    // produce: up to RT_WL_PER_LANE entries per lane and pass
-                    if (lane == 0) *wcnt = 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    const int n_mine = min((int)__popcll(cand4), RT_WL_PER_LANE);
-                    unsigned int off = 0u;
-                    if (n_mine) off = atomicAdd(wcnt, (unsigned int)n_mine);
-#pragma unroll
-                    for (int j = 0; j < RT_WL_PER_LANE; ++j) {
-                        if (j < n_mine) {
-                            const int q = (int)__builtin_ctzll(cand4);
-                            cand4 &= cand4 - 1ull;
-                            went[off + j] = (unsigned short)((lane << 6) | q);
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const int n_ent = __builtin_amdgcn_readfirstlane((int)*(volatile unsigned int *)wcnt);
-                    // consume: 64 items per round
-                    for (int ib = 0; ib < n_ent; ib += 64) {
-                        const bool have = ib + lane < n_ent;
-                        const int e = have ? (int)went[ib + lane] : 0;
-                        const int src = e >> 6, q = e & 63;
-                        // the owner's ray (every lane takes part in the permutes)
-                        const float fox = __shfl(ox, src, 64), foy = __shfl(oy, src, 64), foz = __shfl(oz, src, 64);
-                        const float fdx = __shfl(dx, src, 64), fdy = __shfl(dy, src, 64), fdz = __shfl(dz, src, 64);
-                        const float fra = __shfl(ra, src, 64), frinv = __shfl(rinv_a, src, 64), fbt = __shfl(own_t, src, 64);
-                        if (COUNT) {
-                            c_clusters++;
-                            c_lane_clusters += have ? 1u : 0u;
-                        }
-                        if (have) {
-                            const int base = P.np + (CSIZE + 1) * q;
-                            const float4 *cs = sph + base;
-                            // sphere::hit's discriminant test (object.cuh:47-56) for the cluster's spheres; the roots of
-                            // the few candidates are worked out afterwards, one candidate per lane and round: with 64
-                            // busy lanes some lane has a candidate in every slot, and a sqrt block per slot would run
-                            // for all of them
-                            auto terms = [&](const float4 S, float &hb, float &disc) -> bool {
-                                const float ocx = fox - S.x, ocy = foy - S.y, ocz = foz - S.z;
-                                hb = dot3(ocx, ocy, ocz, fdx, fdy, fdz);
-                                const float cc = fmaf(ocx, ocx, fmaf(ocy, ocy, fmaf(ocz, ocz, -S.w)));
-                                disc = fmaf(hb, hb, -(fra * cc));
-                                return !(disc < 0.0f) && !(hb >= 0.0f && cc >= 0.0f);
-                            };
-                            uint32_t cmask = 0u;
-#pragma unroll
-                            for (int h = 0; h < CSIZE; h += 4) {
-                                const float4 r0 = cs[h], r1 = cs[h + 1], r2 = cs[h + 2], r3 = cs[h + 3];
-                                float hb, disc;
-                                if (terms(r0, hb, disc)) cmask |= 1u << h;
-                                if (terms(r1, hb, disc)) cmask |= 2u << h;
-                                if (terms(r2, hb, disc)) cmask |= 4u << h;
-                                if (terms(r3, hb, disc)) cmask |= 8u << h;
-                            }
-                            float lbt = fbt;
-                            int lid = -1;
-                            while (__builtin_amdgcn_ballot_w64(cmask != 0u) != 0ull) {
-                                if (cmask != 0u) {
-                                    const int h = (int)__builtin_ctz(cmask);
-                                    cmask &= cmask - 1u;
-                                    float hb, disc;
-                                    terms(cs[h], hb, disc);
-                                    if (COUNT) c_cand++;
-                                    const float sq = rt_sqrtf(disc);
-                                    float root = (-hb - sq) * frinv;
-                                    if (root < kTMin || lbt < root) root = (-hb + sq) * frinv;
-                                    if (!(root < kTMin || lbt < root)) {
-                                        bool take = true;
-                                        if (root == lbt && lid >= 0)
-                                            take = list_index_of(P, image, base + h) > list_index_of(P, image, lid);
-                                        if (take) lbt = root, lid = base + h;
-                                    }
-                                }
-                            }
-                            if (lid >= 0) {
-                                const unsigned int li = (RT_ABLATE & 16) ? 0u : (unsigned int)list_index_of(P, image, lid);
-                                const unsigned long long key = ((unsigned long long)__float_as_uint(lbt) << 32) |
-                                                               ((unsigned long long)(0xFFFFu - li) << 16) | (unsigned int)lid;
-                                atomicMin(wkey + src, key);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                // the owner merges the clusters' closest hit with what its prefix found
-                __builtin_amdgcn_wave_barrier();
-                const unsigned long long k = *(volatile unsigned long long *)(wkey + lane);
-                if (active && k != ~0ull) {
-                    const float kt = __uint_as_float((unsigned int)(k >> 32));
-                    const int kid = (int)(k & 0xFFFFu);
-                    bool take = kt < best_t || best_id < 0;
-                    if (!take && kt == best_t) take = (int)(0xFFFFu - ((unsigned int)(k >> 16) & 0xFFFFu)) > list_index_of(P, image, best_id);
-                    if (take) best_t = kt, best_id = kid;
-                }
-            }
             if (active) {
 #undef RT_SPHERE_TEST
 
-            // axis-aligned rects: xy_rect/xz_rect/yz_rect::hit, object.cuh:105-192
-            for (int j = 0; j < nr; ++j) {
-                const float4 q0 = rect[2 * j], q1 = rect[2 * j + 1];
-                const int axis = __float_as_int(q1.y);  // 0: z = k, 1: y = k, 2: x = k
-                float ok, dk, oa, da, ob, db;
-                if (axis == 0) ok = oz, dk = dz, oa = ox, da = dx, ob = oy, db = dy;
-                else if (axis == 1) ok = oy, dk = dy, oa = ox, da = dx, ob = oz, db = dz;
-                else ok = ox, dk = dx, oa = oy, da = dy, ob = oz, db = dz;
-                const float t = (q1.x - ok) / dk;
-                if (!(t < kTMin || t > best_t)) {
-                    const float pa = fmaf(t, da, oa), pb = fmaf(t, db, ob);
-                    if (!(pa < q0.x || pa > q0.y || pb < q0.z || pb > q0.w)) {
-                        bool take = true;
-                        if (t == best_t && best_id >= 0)  // tie: the later list entry wins
-                            take = list_index_of(P, image, ns + j) > list_index_of(P, image, best_id);
-                        if (take) {
-                            best_t = t;
-                            best_id = ns + j;
-                        }
+            // ---- rectangles, cylinders and triangles that are tested for every query: all of them in the searches without a grid
+            // (the reference's loop), the oversized ones in the grid kernels -- plus, for a lane whose origin lies beyond the reach
+            // of the cells' lists (far_scan), the listed ones as well
+            if (!SPH) {
+                const bool any_far = GRID && __builtin_amdgcn_ballot_w64(far_scan) != 0ull;
+                const int nr_loop = (GRID && !any_far) ? P.nr_a : nr, nc_loop = (GRID && !any_far) ? P.nc_a : nc;
+                const int nt_loop = EXT ? ((GRID && !any_far) ? P.nt_a : nt) : 0;
+                for (int j = 0; j < nr_loop; ++j)
+                    if (!GRID || j < P.nr_a || far_scan) test_rect(j);
+                // the boxes of cylinders and triangles: the box-test values once more (see box_params)
+                BoxP bq = {};
+                if (CULL && (nc_loop > 0 || nt_loop > 0)) bq = box_params();
+                for (int k = 0; k < nc_loop; ++k) {
+                    const bool mine = !GRID || k < P.nc_a || far_scan;
+                    if (CULL) {
+                        blim = best_t * 1.0001f;  // the cylinder's world-space box, same margin (the object-space quadratic has the
+                                 // same error structure as the sphere test: ~1e-3 |o| in space)
+                        const float4 *cb = cyl + RT_CYL_STRIDE * k + 4;
+                        if (__builtin_amdgcn_ballot_w64(mine && slab_live(bq, cb[0], cb[1])) == 0ull) continue;
                     }
+                    if (mine) test_cyl(k);
                 }
-            }
-
-            // the boxes of cylinders and triangles: the box-test values once more (see box_params)
-            BoxP bq = {};
-            if (CULL && (nc > 0 || (EXT && nt > 0))) bq = box_params();
-            // cylinders: cylinder::hit + quadratic, object.cuh:199-214, 233-290
-            for (int k = 0; k < nc; ++k) {
-                if (CULL) {
-                    blim = best_t * 1.0001f;  // the cylinder's world-space box, same margin (the object-space quadratic has the
-                             // same error structure as the sphere test: ~1e-3 |o| in space)
-                    const float4 *cb = hot + P.off_cbox + 2 * k;
-                    if (__builtin_amdgcn_ballot_w64(slab_live(bq, cb[0], cb[1])) == 0ull) continue;
-                }
-                const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2], pr = cyl[4 * k + 3];
-                const float oox = fmaf(r0.x, ox, fmaf(r0.y, oy, fmaf(r0.z, oz, r0.w)));
-                const float ooy = fmaf(r1.x, ox, fmaf(r1.y, oy, fmaf(r1.z, oz, r1.w)));
-                const float ooz = fmaf(r2.x, ox, fmaf(r2.y, oy, fmaf(r2.z, oz, r2.w)));
-                const float odx = fmaf(r0.x, dx, fmaf(r0.y, dy, r0.z * dz));
-                const float ody = fmaf(r1.x, dx, fmaf(r1.y, dy, r1.z * dz));
-                const float odz = fmaf(r2.x, dx, fmaf(r2.y, dy, r2.z * dz));
-                const float qa = fmaf(odx, odx, ody * ody);
-                const float qb = 2.0f * fmaf(odx, oox, ody * ooy);
-                const float qc = fmaf(oox, oox, fmaf(ooy, ooy, -pr.x));
-                const float delta = fmaf(qb, qb, -((4.0f * qa) * qc));
-                if (!(delta < 0.0f)) {
-                    const float sq = rt_sqrtf(delta);
-                    float t0 = (-0.5f * (qb - sq)) / qa;
-                    float t1 = (-0.5f * (qb + sq)) / qa;
-                    if (t0 > t1) {
-                        const float tmp = t0;
-                        t0 = t1;
-                        t1 = tmp;
+                for (int k = 0; k < nt_loop; ++k) {
+                    const bool mine = !GRID || k < P.nt_a || far_scan;
+                    if (CULL) {
+                        blim = best_t * 1.0001f;
+                        const float4 *tb = tri + RT_TRI_STRIDE * k + 3;
+                        if (__builtin_amdgcn_ballot_w64(mine && slab_live(bq, tb[0], tb[1])) == 0ull) continue;
                     }
-                    bool ok = !(t0 > best_t || t1 < kTMin);
-                    float t = t0;
-                    if (ok && t0 < kTMin) {
-                        t = t1;
-                        if (t > best_t) ok = false;
-                    }
-                    if (ok) {
-                        float opz = fmaf(t, odz, ooz);
-                        if (opz < pr.y || opz > pr.z) {
-                            if (t == t1) ok = false;
-                            else {
-                                t = t1;
-                                if (t > best_t || t < kTMin) ok = false;
-                                else {
-                                    opz = fmaf(t, odz, ooz);
-                                    if (opz < pr.y || opz > pr.z) ok = false;
-                                }
-                            }
-                        }
-                    }
-                    if (ok) {
-                        bool take = true;
-                        if (t == best_t && best_id >= 0)
-                            take = list_index_of(P, image, ns + nr + k) > list_index_of(P, image, best_id);
-                        if (take) {
-                            best_t = t;
-                            best_id = ns + nr + k;
-                        }
-                    }
-                }
-            }
-            // triangles: hit_triangle, taichi-version/hittable.py:38-71 -- the plane of the triangle (its unit normal
-            // turned towards the ray origin), then four same-side tests of the plane point
-            for (int k = 0; EXT && k < nt; ++k) {
-                if (CULL) {
-                    blim = best_t * 1.0001f;
-                    const float4 *tb = hot + P.off_tbox + 2 * k;
-                    if (__builtin_amdgcn_ballot_w64(slab_live(bq, tb[0], tb[1])) == 0ull) continue;
-                }
-                const float4 r0 = tri[3 * k], r1 = tri[3 * k + 1], r2 = tri[3 * k + 2];
-                float rix, riy, riz, root;
-                if (tri_plane(r0, r1, r2, rix, riy, riz, root) && !(root < kTMin || root > best_t)) {
-                    const float e21x = r1.x - r0.x, e21y = r1.y - r0.y, e21z = r1.z - r0.z;
-                    const float e31x = r2.x - r0.x, e31y = r2.y - r0.y, e31z = r2.z - r0.z;
-                    const float e32x = r2.x - r1.x, e32y = r2.y - r1.y, e32z = r2.z - r1.z;
-                    const float a1x = rix - r0.x, a1y = riy - r0.y, a1z = riz - r0.z;
-                    const float a2x = rix - r1.x, a2y = riy - r1.y, a2z = riz - r1.z;
-                    float px_, py_, pz_, qx_, qy_, qz_;
-                    cross3(a1x, a1y, a1z, e21x, e21y, e21z, px_, py_, pz_);
-                    cross3(e31x, e31y, e31z, e21x, e21y, e21z, qx_, qy_, qz_);
-                    const float n1 = dot3(px_, py_, pz_, qx_, qy_, qz_);
-                    cross3(a2x, a2y, a2z, -e21x, -e21y, -e21z, px_, py_, pz_);
-                    cross3(e32x, e32y, e32z, -e21x, -e21y, -e21z, qx_, qy_, qz_);
-                    const float n2 = dot3(px_, py_, pz_, qx_, qy_, qz_);
-                    cross3(a1x, a1y, a1z, e31x, e31y, e31z, px_, py_, pz_);
-                    cross3(e21x, e21y, e21z, e31x, e31y, e31z, qx_, qy_, qz_);
-                    const float n3 = dot3(px_, py_, pz_, qx_, qy_, qz_);
-                    cross3(a2x, a2y, a2z, e32x, e32y, e32z, px_, py_, pz_);
-                    cross3(-e21x, -e21y, -e21z, e32x, e32y, e32z, qx_, qy_, qz_);
-                    const float n4 = dot3(px_, py_, pz_, qx_, qy_, qz_);
-                    if (n1 > 0.0f && n2 > 0.0f && n3 > 0.0f && n4 > 0.0f) {
-                        bool take = true;
-                        if (root == best_t && best_id >= 0)
-                            take = list_index_of(P, image, ns + nr + nc + k) > list_index_of(P, image, best_id);
-                        if (take) {
-                            best_t = root;
-                            best_id = ns + nr + nc + k;
-                        }
-                    }
+                    if (mine) test_tri(k);
                 }
             }
             // (a lane whose grid walk was cut short has no result yet: its query goes on in the next iteration)
@@ -1268,7 +1101,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     kind = __float_as_int(rc.z);
                 } else if (best_id < ns + nr + nc) {
                     const int k = best_id - ns - nr;
-                    const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2];
+                    const float4 r0 = cyl[RT_CYL_STRIDE * k], r1 = cyl[RT_CYL_STRIDE * k + 1], r2 = cyl[RT_CYL_STRIDE * k + 2];
                     const float4 *cc4 = image + P.off_cyl_cold + 4 * k;
                     const float4 m0 = cc4[0], m1 = cc4[1], m2 = cc4[2];
                     const float oox = fmaf(r0.x, ox, fmaf(r0.y, oy, fmaf(r0.z, oz, r0.w)));
@@ -1292,7 +1125,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     kind = __float_as_int(cc4[3].z);
                 } else if (EXT) {  // triangle, taichi-version/hittable.py:254-259: the stored unit normal, turned against the ray
                     const int k = best_id - ns - nr - nc;
-                    const float tnx = tri[3 * k].w, tny = tri[3 * k + 1].w, tnz = tri[3 * k + 2].w;
+                    const float tnx = tri[RT_TRI_STRIDE * k].w, tny = tri[RT_TRI_STRIDE * k + 1].w, tnz = tri[RT_TRI_STRIDE * k + 2].w;
                     px = fmaf(best_t, dx, ox), py = fmaf(best_t, dy, oy), pz = fmaf(best_t, dz, oz);
                     front = dot3(dx, dy, dz, tnx, tny, tnz) < 0.0f;
                     nx = front ? tnx : -tnx, ny = front ? tny : -tny, nz = front ? tnz : -tnz;
@@ -1321,7 +1154,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         tv = (pb - q0r.z) / (q0r.w - q0r.z);
                     } else if (best_id < ns + nr + nc) {  // object.cuh:283-288, in the cylinder's object space
                         const int k = best_id - ns - nr;
-                        const float4 r0 = cyl[4 * k], r1 = cyl[4 * k + 1], r2 = cyl[4 * k + 2], pr = cyl[4 * k + 3];
+                        const float4 r0 = cyl[RT_CYL_STRIDE * k], r1 = cyl[RT_CYL_STRIDE * k + 1], r2 = cyl[RT_CYL_STRIDE * k + 2], pr = cyl[RT_CYL_STRIDE * k + 3];
                         const float oox = fmaf(r0.x, ox, fmaf(r0.y, oy, fmaf(r0.z, oz, r0.w)));
                         const float ooy = fmaf(r1.x, ox, fmaf(r1.y, oy, fmaf(r1.z, oz, r1.w)));
                         const float ooz = fmaf(r2.x, ox, fmaf(r2.y, oy, fmaf(r2.z, oz, r2.w)));
@@ -1334,7 +1167,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                         tv = (opz - pr.y) / (pr.z - pr.y);
                     } else {  // hittable.py:54-58, 233: area weights of the plane point, uv = u1 w1 + u2 w2 + u3 w3
                         const int k = best_id - ns - nr - nc;
-                        const float4 r0 = tri[3 * k], r1 = tri[3 * k + 1], r2 = tri[3 * k + 2];
+                        const float4 r0 = tri[RT_TRI_STRIDE * k], r1 = tri[RT_TRI_STRIDE * k + 1], r2 = tri[RT_TRI_STRIDE * k + 2];
                         float rix, riy, riz, root;
                         tri_plane(r0, r1, r2, rix, riy, riz, root);
                         const float a1x = rix - r0.x, a1y = riy - r0.y, a1z = riz - r0.z;
@@ -1392,7 +1225,7 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         tick(3);
         // ---- (3) res += ray_color(...), main.cu:100 -- exact fixed-point add into the tile
         if (path_done) {
-            if (!(RT_ABLATE & 2)) {
+            {
                 const unsigned long long fr = radiance_to_fixed(L_r), fg = radiance_to_fixed(L_g), fb = radiance_to_fixed(L_b);
                 if (slot >= 0) {
                     unsigned long long *g = acc + (size_t)slot * 3;
@@ -1413,9 +1246,6 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         // ---- (4) refill: lanes without a live path take new samples
         // (render()'s sample loop, main.cu:95-101; camera::get_ray camera.h:32-39)
         float u = 0, v = 0;    // jitter of the sample a lane starts (main.cu:96-97)
-#if RT_UNDEF_INIT > 1
-        asm volatile("" : "=v"(u), "=v"(v));  // (read by the lanes that start a path)
-#endif
         bool started = false;  // this lane starts a new path in this iteration
         const bool need = !active;
         const unsigned long long idle = __ballot(need);
@@ -1471,20 +1301,16 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                     const int s_end = sample_first + sample_count;
                     if (s_stop > s_end) s_stop = s_end;
                     c_pool = (s_stop - c_sbegin) * 64;  // pool item k = (pixel k & 63, sample c_sbegin + (k >> 6))
-#if RT_ITEM_SCALARS
                     // (the item's values are the same in every lane; said so, they live in scalar registers instead of five of
                     //  the 72 vector registers this kernel spills from)
                     c_x0 = __builtin_amdgcn_readfirstlane(c_x0), c_band = __builtin_amdgcn_readfirstlane(c_band);
                     c_sbegin = __builtin_amdgcn_readfirstlane(c_sbegin), c_pool = __builtin_amdgcn_readfirstlane(c_pool);
-#endif
                     cursor = 0;
                     mine = 0;
                     c_valid = true;
                     int hx_unused, hlr_unused;
                     home_pixel(c_x0, c_band, hx_unused, hlr_unused, c_hy, c_hvalid);
-#if RT_ITEM_SCALARS
                     c_hvmask = __builtin_amdgcn_ballot_w64(c_hvalid != 0);
-#endif
                 }
             }
             bool start = false;
@@ -1497,14 +1323,10 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 sp = k & 63;
                 // row and validity of pixel sp live in lane sp's registers (all lanes take part)
                 spy = __shfl(c_hy, sp, 64);
-#if RT_ITEM_SCALARS
                 // (on-image bit of pixel sp from the item's lane mask: a select and a bit-field extract instead of a second
                 //  cross-lane read)
                 const uint32_t hv_word = (sp & 32) ? (uint32_t)(c_hvmask >> 32) : (uint32_t)c_hvmask;
                 const int pv = (int)((hv_word >> (sp & 31)) & 1u);
-#else
-                const int pv = __shfl(c_hvalid, sp, 64);
-#endif
                 spx = c_x0 + (sp & 7);
                 ss = c_sbegin + (k >> 6);
                 start = need && c_valid && k < c_pool && pv != 0;
@@ -1545,12 +1367,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
         const bool need_s = kind >= 0 && kind <= MK_METAL;
         const bool need_d = started && (P.flags & RT_FLAG_DEFOCUS_BLUR) != 0u;
         float sx = 0, sy = 0, sz = 0, sl2 = 1;
-#if RT_UNDEF_INIT > 1
-        asm volatile("" : "=v"(sx), "=v"(sy), "=v"(sz), "=v"(sl2));  // (read by the lanes that ran the loop below)
-#endif
         if (need_s || need_d) {
             if (RT_PRIO_R != RT_PRIO_F) __builtin_amdgcn_s_setprio(RT_PRIO_R);
-#if RT_REJ_SELECT
             // The three draws of an attempt written out on the generator's four state words (xor128_next, philox.h): every
             // lane computes the third value, and the lanes that sample a disk do not keep it -- their state advances by two
             // draws, the others' by three, through four selects on a loop-invariant mask.  With the third draw behind a
@@ -1569,17 +1387,8 @@ __global__ __launch_bounds__(256, (CULL == 0 ? RT_WAVES_LINEAR : RT_WAVES_PER_SI
                 x = need_s ? w : z, y = need_s ? n1 : w, z = need_s ? n2 : n1, w = need_s ? n3 : n2;
                 if (COUNT) rng.draws += need_s ? 3u : 2u;
                 sl2 = dot3(sx, sy, sz, sx, sy, sz);  // disk: fma(x, x, y * y) -- the product with sz = 0 adds an exact zero
-            } while (RT_ABLATE_REJ(sl2 >= 1.0f));
+            } while (sl2 >= 1.0f);
             rng.g.x = x, rng.g.y = y, rng.g.z = z, rng.g.w = w;
-#else
-            do {
-                sx = rng_pm1<COUNT>(rng);
-                sy = rng_pm1<COUNT>(rng);
-                sz = 0.0f;
-                if (need_s) sz = rng_pm1<COUNT>(rng);
-                sl2 = dot3(sx, sy, sz, sx, sy, sz);  // disk: fma(x, x, y * y) -- the product with sz = 0 adds an exact zero
-            } while (RT_ABLATE_REJ(sl2 >= 1.0f));
-#endif
             if (RT_PRIO_R != RT_PRIO_F) __builtin_amdgcn_s_setprio(RT_PRIO_F);
         }
         if (RT_PRIO_S != RT_PRIO_F) __builtin_amdgcn_s_setprio(RT_PRIO_S);
@@ -1749,139 +1558,118 @@ __global__ __launch_bounds__(256) void finalize_kernel(const unsigned long long 
 template __global__ void render_kernel<RT_ISA_ONLY>(const RenderParams, const float4 *__restrict__, unsigned long long *__restrict__,
                                                     unsigned int *__restrict__, DevCounters *__restrict__);
 #else
-// launchers used by render_host.hip
-// X(variant id, POOL, PREFETCH, SCALAR, CULL).  0 is the product default (the uniform-grid walk, CULL 5); the others are
-// ablations and fallbacks with identical results: bit 0 = no tile pool (strict one-lane-per-pixel), bit 1 = no LDS
-// prefetch, bit 3 = tables through global memory instead of LDS, bit 4 = no culling at all (every sphere tested for
-// every query: the reference's linear hittable_list scan), bit 5 = wave-level cluster votes, bit 6 = per-lane cluster
-// lists through the two-level box hierarchy (round 1's default), bit 7 = per-lane cluster lists through the range
-// tables (the fallback for scenes without a grid), 4 = range tables with work-balanced cluster tests;
-// 40 / 104 / 136 = the grid / the box hierarchy / the range tables with all tables in global memory (chosen
-// automatically for scenes too large for LDS)
-#define RT_VARIANT_TABLE(X)        \
-    X(0, true, true, false, 5)     \
-    X(2, true, true, false, 6)     \
-    X(1, false, true, false, 5)    \
-    X(4, true, true, false, 4)     \
-    X(8, true, true, true, 1)      \
-    X(16, true, true, false, 0)    \
-    X(17, false, true, false, 0)   \
-    X(19, false, false, false, 0)  \
-    X(24, true, true, true, 0)     \
-    X(32, true, true, false, 1)    \
-    X(40, true, true, true, 5)     \
-    X(44, true, true, true, 7)     \
-    X(64, true, true, false, 2)    \
-    X(104, true, true, true, 2)    \
-    X(128, true, true, false, 3)   \
-    X(136, true, true, true, 3)
-// variants that also exist with EXT (triangles, image textures): the default, its global-table form, the flat scan, and the
-// range tables (scenes whose clustered spheres have no grid)
-#define RT_EXT_TABLE(X)            \
-    X(0, true, true, false, 5)     \
-    X(16, true, true, false, 0)    \
-    X(40, true, true, true, 5)     \
-    X(128, true, true, false, 3)   \
-    X(136, true, true, true, 3)
-// every variant exists for both cluster sizes (the linear scans ignore it)
-#define RT_WITH_CSIZE(CALL8, CALL16) \
-    if (cluster == 16) { CALL16; } else { CALL8; }
+// ---------------------------------------------------------------- launchers used by render_host.hip
+// X(variant id, POOL, SCALAR, CULL, SPH).  The host resolves variant 0 to one of the four PRODUCT instances:
+//    2  compact grid one cell high, tables in LDS (RTIOW)         6  compact grid, 3-D walk, tables in LDS (sphere-only scenes)
+//   36  wide grid tables in LDS (scenes with other primitives)   44  wide grid tables in global memory (large scenes)
+// and the wide ones also exist with EXT (triangles, image textures): six render_kernel instances in a product build
+// (make ABLATIONS=0).  The default build (RTMI_ABLATIONS=1: tests, bench.py) adds the measurement variants -- same image, bit for
+// bit -- and the counting kernels:
+//    1  variant 6 with strict one-lane-per-pixel ownership       40  variant 6 with its tables in global memory
+//   16  no culling: the reference's linear hittable_list scan    17  ... with strict ownership       24  ... tables in global memory
+//   32  wave-level cluster votes      64  per-lane cluster lists through the two-level box hierarchy (round 1's default)
+//  128  per-lane cluster lists through the range tables (first half of round 2)
+#define RT_PRODUCT_TABLE(X)          \
+    X(2, true, false, 6, true)       \
+    X(6, true, false, 5, true)       \
+    X(36, true, false, 7, false)     \
+    X(44, true, true, 7, false)
+#define RT_PRODUCT_EXT_TABLE(X)      \
+    X(36, true, false, 7, false)     \
+    X(44, true, true, 7, false)
+#if RTMI_ABLATIONS
+#define RT_ABLATION_TABLE(X)         \
+    X(1, false, false, 5, true)      \
+    X(40, true, true, 5, true)       \
+    X(16, true, false, 0, false)     \
+    X(17, false, false, 0, false)    \
+    X(24, true, true, 0, false)      \
+    X(32, true, false, 1, false)     \
+    X(64, true, false, 2, false)     \
+    X(128, true, false, 3, false)
+#define RT_ABLATION_EXT_TABLE(X)     \
+    X(16, true, false, 0, false)     \
+    X(24, true, true, 0, false)
+// counting kernels (rt_render_hip_count): X(variant, SCALAR, CULL, EXT, SPH)
+#define RT_COUNT_TABLE(X)            \
+    X(6, false, 5, false, true)      \
+    X(36, false, 7, true, false)     \
+    X(44, true, 7, true, false)      \
+    X(64, false, 2, false, false)    \
+    X(128, false, 3, false, false)
+#else
+#define RT_ABLATION_TABLE(X)
+#define RT_ABLATION_EXT_TABLE(X)
+#define RT_COUNT_TABLE(X)
+#endif
+#define RT_VARIANT_TABLE(X) RT_PRODUCT_TABLE(X) RT_ABLATION_TABLE(X)
+#define RT_EXT_TABLE(X) RT_PRODUCT_EXT_TABLE(X) RT_ABLATION_EXT_TABLE(X)
 
-void launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
+bool has_ablations() { return RTMI_ABLATIONS != 0; }
+
+// launches the instance of a RESOLVED variant (never 0); false: no such build
+bool launch_render(const RenderParams &P, const void *image, unsigned long long *acc, unsigned int *queue,
                    DevCounters *counters, size_t lds_bytes, unsigned grid, hipStream_t stream, unsigned variant, bool ext) {
     const float4 *img = (const float4 *)image;
     const dim3 g(grid), t(256);
-    const int cluster = P.cluster;
     if (counters) {
-#define RT_COUNT_LAUNCH(SCALAR, CULL)                                                                                                       \
-    RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<true, true, true, SCALAR, CULL, 8>), g, t, lds_bytes, stream, P, img, acc, queue, counters),  \
-                  hipLaunchKernelGGL((render_kernel<true, true, true, SCALAR, CULL, 16>), g, t, lds_bytes, stream, P, img, acc, queue, counters))
-        if (variant == 128) { RT_COUNT_LAUNCH(false, 3) }
-        else if (variant == 136) { RT_COUNT_LAUNCH(true, 3) }
-        else if (variant == 40) { RT_COUNT_LAUNCH(true, 5) }
-        else if (variant == 104) { RT_COUNT_LAUNCH(true, 2) }
-        else if (variant == 64) { RT_COUNT_LAUNCH(false, 2) }
-        else { RT_COUNT_LAUNCH(false, 5) }
-#undef RT_COUNT_LAUNCH
-        return;
+#define RT_LAUNCH_COUNT(V, SCALAR, CULL, EXT, SPH)                                                                                         \
+    if (variant == V) {                                                                                                                     \
+        hipLaunchKernelGGL((render_kernel<true, true, SCALAR, CULL, EXT, SPH>), g, t, lds_bytes, stream, P, img, acc, queue, counters);   \
+        return true;                                                                                                                        \
+    }
+        RT_COUNT_TABLE(RT_LAUNCH_COUNT)
+#undef RT_LAUNCH_COUNT
+        return false;
     }
     DevCounters *none = nullptr;
     if (ext) {
-#define RT_LAUNCH_EXT(V, POOL, PRE, SCALAR, CULL)                                                                                          \
-    case V:                                                                                                                                 \
-        RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 8, true>), g, t, lds_bytes, stream, P, img, acc, queue, none),  \
-                      hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 16, true>), g, t, lds_bytes, stream, P, img, acc, queue, none)) \
-        break;
-        switch (variant) {
-            RT_EXT_TABLE(RT_LAUNCH_EXT)
-        default: break;
-        }
+#define RT_LAUNCH_EXT(V, POOL, SCALAR, CULL, SPH)                                                                                          \
+    if (variant == V) {                                                                                                                     \
+        hipLaunchKernelGGL((render_kernel<false, POOL, SCALAR, CULL, true, false>), g, t, lds_bytes, stream, P, img, acc, queue, none);   \
+        return true;                                                                                                                        \
+    }
+        RT_EXT_TABLE(RT_LAUNCH_EXT)
 #undef RT_LAUNCH_EXT
-        return;
+        return false;
     }
-    // sphere-only scenes: the default kernel's builds without the other primitives (RTMI_NO_SPH=1 keeps the general build: A/B knob)
-    static const bool no_sph = getenv("RTMI_NO_SPH") != nullptr;
-    if (!no_sph && (variant == 0 || variant == 2) && P.nr + P.nc + P.nt == 0) {
-        if (variant == 0) {
-            RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, true, true, false, 5, 8, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, none),
-                          hipLaunchKernelGGL((render_kernel<false, true, true, false, 5, 16, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, none))
-        } else {
-            RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, true, true, false, 6, 8, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, none),
-                          hipLaunchKernelGGL((render_kernel<false, true, true, false, 6, 16, false, true>), g, t, lds_bytes, stream, P, img, acc, queue, none))
-        }
-        return;
+#define RT_LAUNCH(V, POOL, SCALAR, CULL, SPH)                                                                                              \
+    if (variant == V) {                                                                                                                     \
+        hipLaunchKernelGGL((render_kernel<false, POOL, SCALAR, CULL, false, SPH>), g, t, lds_bytes, stream, P, img, acc, queue, none);    \
+        return true;                                                                                                                        \
     }
-#define RT_LAUNCH(V, POOL, PRE, SCALAR, CULL)                                                                                              \
-    case V:                                                                                                                                 \
-        RT_WITH_CSIZE(hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 8>), g, t, lds_bytes, stream, P, img, acc, queue, none),  \
-                      hipLaunchKernelGGL((render_kernel<false, POOL, PRE, SCALAR, CULL, 16>), g, t, lds_bytes, stream, P, img, acc, queue, none)) \
-        break;
-    switch (variant) {
-        RT_VARIANT_TABLE(RT_LAUNCH)
-    default: break;
-    }
+    RT_VARIANT_TABLE(RT_LAUNCH)
 #undef RT_LAUNCH
+    return false;
 }
 
 // resident workgroups per CU of a variant at this dynamic-LDS size (advisory; an over-estimate only
 // leaves late workgroups that find the queue empty)
-int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, int cluster, bool ext) {
+int blocks_per_cu(unsigned variant, bool count, size_t lds_bytes, bool ext) {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
-    if (ext) {
-#define RT_OCC_EXT(V, POOL, PRE, SCALAR, CULL)                                                                                              \
-    if (variant == V) {                                                                                                                      \
-        RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL, 8, true>, 256, lds_bytes), \
-                      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL, 16, true>, 256, lds_bytes)) \
-    }
+    if (count) {
+#define RT_OCC_COUNT(V, SCALAR, CULL, EXT, SPH) \
+    if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, SCALAR, CULL, EXT, SPH>, 256, lds_bytes);
+        RT_COUNT_TABLE(RT_OCC_COUNT)
+#undef RT_OCC_COUNT
+    } else if (ext) {
+#define RT_OCC_EXT(V, POOL, SCALAR, CULL, SPH) \
+    if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, SCALAR, CULL, true, false>, 256, lds_bytes);
         RT_EXT_TABLE(RT_OCC_EXT)
 #undef RT_OCC_EXT
-    } else if (count) {
-#define RT_COUNT_OCC(SCALAR, CULL)                                                                                                          \
-    RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 8>, 256, lds_bytes),   \
-                  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<true, true, true, SCALAR, CULL, 16>, 256, lds_bytes))
-        if (variant == 128) { RT_COUNT_OCC(false, 3) }
-        else if (variant == 136) { RT_COUNT_OCC(true, 3) }
-        else if (variant == 40) { RT_COUNT_OCC(true, 5) }
-        else if (variant == 104) { RT_COUNT_OCC(true, 2) }
-        else if (variant == 64) { RT_COUNT_OCC(false, 2) }
-        else { RT_COUNT_OCC(false, 5) }
-#undef RT_COUNT_OCC
     } else {
-#define RT_OCC(V, POOL, PRE, SCALAR, CULL)                                                                                                  \
-    if (variant == V) {                                                                                                                      \
-        RT_WITH_CSIZE(e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL, 8>, 256, lds_bytes), \
-                      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, PRE, SCALAR, CULL, 16>, 256, lds_bytes)) \
-    }
+#define RT_OCC(V, POOL, SCALAR, CULL, SPH) \
+    if (variant == V) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_kernel<false, POOL, SCALAR, CULL, false, SPH>, 256, lds_bytes);
         RT_VARIANT_TABLE(RT_OCC)
 #undef RT_OCC
     }
     return (e == hipSuccess && n > 0) ? n : 4;
 }
 
-// candidate search of a variant (the CULL template argument): decides how much of the hot table is staged
+// candidate search of a variant (the CULL template argument): decides how much of the hot table is staged; -1: no such build
 int variant_cull_mode(unsigned variant) {
-#define RT_MODE(V, POOL, PRE, SCALAR, CULL) \
+#define RT_MODE(V, POOL, SCALAR, CULL, SPH) \
     if (variant == V) return CULL;
     RT_VARIANT_TABLE(RT_MODE)
 #undef RT_MODE
@@ -1890,20 +1678,22 @@ int variant_cull_mode(unsigned variant) {
 
 // does the variant have a build with triangles and image textures?
 bool variant_has_ext(unsigned variant) {
-#define RT_HAS_EXT(V, POOL, PRE, SCALAR, CULL) \
+#define RT_HAS_EXT(V, POOL, SCALAR, CULL, SPH) \
     if (variant == V) return true;
     RT_EXT_TABLE(RT_HAS_EXT)
 #undef RT_HAS_EXT
     return false;
 }
 
-bool variant_exists(unsigned variant) {
-#define RT_HAS(V, POOL, PRE, SCALAR, CULL) \
+bool variant_has_count(unsigned variant) {
+#define RT_HAS_COUNT(V, SCALAR, CULL, EXT, SPH) \
     if (variant == V) return true;
-    RT_VARIANT_TABLE(RT_HAS)
-#undef RT_HAS
+    RT_COUNT_TABLE(RT_HAS_COUNT)
+#undef RT_HAS_COUNT
     return false;
 }
+
+bool variant_exists(unsigned variant) { return variant == 0 || variant_cull_mode(variant) >= 0; }
 
 __global__ void item_params_kernel(unsigned int *queue, ItemParams ip) {
     int *dst = reinterpret_cast<int *>(queue) + RT_ITEM_PARAMS_AT;
@@ -1926,28 +1716,15 @@ void launch_finalize(const unsigned long long *acc, float *out, size_t n, hipStr
 int set_max_dynamic_lds(size_t bytes) {
 #define RT_ATTR1(K)                                                                                                  \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return 1;
-    RT_ATTR1((render_kernel<false, true, true, false, 5, 8, false, true>))
-    RT_ATTR1((render_kernel<false, true, true, false, 5, 16, false, true>))
-    RT_ATTR1((render_kernel<false, true, true, false, 6, 8, false, true>))
-    RT_ATTR1((render_kernel<false, true, true, false, 6, 16, false, true>))
-    RT_ATTR1((render_kernel<true, true, true, false, 5, 8>))
-    RT_ATTR1((render_kernel<true, true, true, false, 5, 16>))
-    RT_ATTR1((render_kernel<true, true, true, true, 5, 8>))
-    RT_ATTR1((render_kernel<true, true, true, true, 5, 16>))
-    RT_ATTR1((render_kernel<true, true, true, false, 3, 8>))
-    RT_ATTR1((render_kernel<true, true, true, false, 3, 16>))
-    RT_ATTR1((render_kernel<true, true, true, false, 2, 8>))
-    RT_ATTR1((render_kernel<true, true, true, false, 2, 16>))
-#define RT_ATTR_EXT(V, POOL, PRE, SCALAR, CULL)                        \
-    RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 8, true>)) \
-    RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 16, true>))
-    RT_EXT_TABLE(RT_ATTR_EXT)
-#undef RT_ATTR_EXT
-#define RT_ATTR(V, POOL, PRE, SCALAR, CULL)                      \
-    RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 8>)) \
-    RT_ATTR1((render_kernel<false, POOL, PRE, SCALAR, CULL, 16>))
+#define RT_ATTR(V, POOL, SCALAR, CULL, SPH) RT_ATTR1((render_kernel<false, POOL, SCALAR, CULL, false, SPH>))
     RT_VARIANT_TABLE(RT_ATTR)
 #undef RT_ATTR
+#define RT_ATTR_EXT(V, POOL, SCALAR, CULL, SPH) RT_ATTR1((render_kernel<false, POOL, SCALAR, CULL, true, false>))
+    RT_EXT_TABLE(RT_ATTR_EXT)
+#undef RT_ATTR_EXT
+#define RT_ATTR_COUNT(V, SCALAR, CULL, EXT, SPH) RT_ATTR1((render_kernel<true, true, SCALAR, CULL, EXT, SPH>))
+    RT_COUNT_TABLE(RT_ATTR_COUNT)
+#undef RT_ATTR_COUNT
 #undef RT_ATTR1
     return 0;
 }

@@ -110,7 +110,10 @@ struct TileGroup {
     hipEvent_t ev_gather0 = nullptr, ev_done = nullptr;  // root stream
     std::mutex mu;                       // one frame at a time per group
 
-    ~TileGroup() {
+    ~TileGroup() { release(); }
+    // frees everything and leaves the group as new (also after a failed set-up, so that the next call starts over instead of
+    // finding half of the handles)
+    void release() {
         int cur = 0;
         const bool have = hipGetDevice(&cur) == hipSuccess;
         RcclApi *api = comms.empty() ? nullptr : rccl_api();
@@ -129,20 +132,30 @@ struct TileGroup {
             if (i < streams.size() && streams[i]) (void)hipStreamDestroy(streams[i]);
         }
         if (have) (void)hipSetDevice(cur);
+        streams.clear(), comms.clear(), local.clear(), ev0.clear(), ev1.clear();
+        local_floats = gathered_floats = full_floats = 0;
+        gathered = full = nullptr;
+        ev_gather0 = ev_done = nullptr;
+    }
+    // waits for whatever has been queued on the group's streams (error paths: nothing of a failed frame is left running)
+    void drain() {
+        for (size_t i = 0; i < devices.size() && i < streams.size(); ++i)
+            if (streams[i] && hipSetDevice(devices[i]) == hipSuccess) (void)hipStreamSynchronize(streams[i]);
     }
 };
 
 // never destroyed at process exit (the HIP runtime and RCCL may already be gone by then); rt_tiles_shutdown() frees
 static std::mutex g_groups_mu;
-static std::vector<std::unique_ptr<TileGroup>> &g_groups = *new std::vector<std::unique_ptr<TileGroup>>();
+// (shared ownership: a frame in flight keeps its group alive across rt_tiles_shutdown)
+static std::vector<std::shared_ptr<TileGroup>> &g_groups = *new std::vector<std::shared_ptr<TileGroup>>();
 
-static TileGroup *group_for(const std::vector<int> &devices) {
+static std::shared_ptr<TileGroup> group_for(const std::vector<int> &devices) {
     std::lock_guard<std::mutex> lock(g_groups_mu);
     for (auto &g : g_groups)
-        if (g->devices == devices) return g.get();
+        if (g->devices == devices) return g;
     g_groups.emplace_back(new TileGroup());
     g_groups.back()->devices = devices;
-    return g_groups.back().get();
+    return g_groups.back();
 }
 
 static int ensure(float *&buf, size_t &have, size_t want) {
@@ -201,7 +214,8 @@ extern "C" int rt_render_hip_tiles(const rt_scene *sc, const rt_opts *o, const i
         ~Restore() { (void)hipSetDevice(dev); }
     } restore{prev};
 
-    TileGroup *g = group_for(devs);
+    const std::shared_ptr<TileGroup> gp = group_for(devs);
+    TileGroup *g = gp.get();
     std::lock_guard<std::mutex> frame(g->mu);
     const int N = n_devices;
     // shard geometry: rank r owns row tiles r, r + N, ...; buffers padded to the largest shard (the gather is uniform)
@@ -217,7 +231,9 @@ extern "C" int rt_render_hip_tiles(const rt_scene *sc, const rt_opts *o, const i
     }
     const size_t local_floats = (size_t)pad_rows * row_floats;
 
-    // ---- per-device state
+    // ---- per-device state.  A failure anywhere in the set-up releases the whole group: the next call starts over.
+    RcclApi *api = nullptr;
+    auto set_up = [&]() -> int {
     if (g->streams.empty()) {
         g->streams.assign(N, nullptr), g->local.assign(N, nullptr), g->ev0.assign(N, nullptr), g->ev1.assign(N, nullptr);
         for (int r = 0; r < N; ++r) {
@@ -244,16 +260,27 @@ extern "C" int rt_render_hip_tiles(const rt_scene *sc, const rt_opts *o, const i
     if (rc) return rc;
     rc = ensure(g->full, g->full_floats, std::max<size_t>((size_t)H * row_floats, 1));
     if (rc) return rc;
-    RcclApi *api = rccl_api();
+    api = rccl_api();
     if (!api) {
         set_error("rt_render_hip_tiles: librccl.so.1 not found (dlopen): the framebuffer gather needs RCCL");
         return RT_ERR_HIP;
     }
     if (g->comms.empty()) {
-        g->comms.assign(N, nullptr);
-        NCCL_TRY(api, api->CommInitAll(g->comms.data(), N, devs.data()));
+        std::vector<ncclComm_t> comms(N, nullptr);
+        NCCL_TRY(api, api->CommInitAll(comms.data(), N, devs.data()));
+        g->comms = comms;
+    }
+    return RT_OK;
+    };
+    if (int rc = set_up()) {
+        g->drain();
+        g->release();
+        return rc;
     }
 
+    // ---- the frame.  On an error, what has been queued is waited for before the call returns.
+    auto run_frame = [&]() -> int {
+    int rc = RT_OK;
     // ---- render: every device its row tiles, asynchronously on its own stream
     for (int r = 0; r < N; ++r) {
         HIP_TRY(hipSetDevice(devs[r]));
@@ -289,6 +316,12 @@ extern "C" int rt_render_hip_tiles(const rt_scene *sc, const rt_opts *o, const i
     for (int r = 0; r < N; ++r) {
         HIP_TRY(hipSetDevice(devs[r]));
         HIP_TRY(hipStreamSynchronize(g->streams[r]));
+    }
+    return RT_OK;
+    };
+    if (int rc = run_frame()) {
+        g->drain();
+        return rc;
     }
     if (stats) {
         memset(stats, 0, sizeof *stats);
@@ -346,8 +379,16 @@ extern "C" int rt_shard_place_rows_device(const rt_scene *sc, const rt_opts *o, 
     return RT_OK;
 }
 
-// release the streams, communicators and buffers rt_render_hip_tiles keeps between calls
+// release the streams, communicators and buffers rt_render_hip_tiles keeps between calls (a group with a frame in flight
+// on another thread is released when that frame ends: the frame holds a reference)
 extern "C" void rt_tiles_shutdown(void) {
-    std::lock_guard<std::mutex> lock(g_groups_mu);
-    g_groups.clear();
+    std::vector<std::shared_ptr<TileGroup>> gone;
+    {
+        std::lock_guard<std::mutex> lock(g_groups_mu);
+        gone.swap(g_groups);
+    }
+    for (auto &g : gone) {
+        std::lock_guard<std::mutex> frame(g->mu);  // (waits for a frame in flight)
+    }
+    gone.clear();
 }

@@ -22,7 +22,7 @@ def test_header_symbols_exported(rtmi):
 
 
 def test_abi_version_and_errors(rtmi):
-    assert rtmi.abi_version() == 2
+    assert rtmi.abi_version() == 3
     lib = ctypes.CDLL(rtmi.LIB_PATH)
     lib.rt_status_string.restype = ctypes.c_char_p
     assert lib.rt_status_string(0) == b"ok"

@@ -29,6 +29,15 @@ def test_gpus_n_without_launcher_refuses_fewer_devices():
     assert p.stdout.strip() == ""  # no JSON line that could be mistaken for a measurement
 
 
+def test_tiles_abi_mode_refuses_fewer_devices():
+    """`bench.py --tiles-abi --gpus N` (one process, rt_render_hip_tiles) on fewer than N devices: an error, no JSON line."""
+    import torch
+    n = max(2, torch.cuda.device_count() + 1)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiles-abi", "--gpus", str(n)], capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and "refusing" in p.stderr and p.stdout.strip() == ""
+
+
 def test_world_size_mismatch_is_an_error():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,

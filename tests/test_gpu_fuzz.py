@@ -34,7 +34,8 @@ def test_random_schedules_equal_the_checker(rtmi, rtcheck, scenes_dir, fuzz_seed
         tile_rows = int(rng.choice([1, 3, 8, 8, 16]))
         stride = int(rng.integers(1, 6))
         tf = int(rng.integers(0, stride))
-        variant = int(rng.choice([0, 0, 0, 1, 64, 32, 40, 128]))
+        # (the compact-table variants for the sphere-only scene, the wide-table ones for the others)
+        variant = int(rng.choice([0, 0, 0, 1, 2, 6, 64, 32, 40, 128] if kind == 0 else [0, 0, 0, 36, 44, 16, 64, 32, 128]))
         o = rtmi.Opts(seed=int(rng.integers(0, 2**31)), sample_first=first, sample_count=count, spp_chunk=chunk,
                       tile_rows=tile_rows, tile_first=tf, tile_stride=stride, variant=variant)
         rows = sc.shard_global_rows(o)
@@ -51,8 +52,8 @@ def test_random_schedules_equal_the_checker(rtmi, rtcheck, scenes_dir, fuzz_seed
 @pytest.mark.parametrize("fuzz_seed", [21, 22])
 def test_random_geometry_every_candidate_search_equals_the_flat_scan(rtmi, rtcheck, fuzz_seed):
     """Random scenes -- sheets, volumes, a few big spheres, 20 to 2500 small ones, random cameras (inside the cloud
-    too) -- through every candidate search: range tables (LDS and global tables), box hierarchy, wave votes,
-    work-balanced tests where one window suffices; all equal to the flat scan, and sampled rows to the CPU checker."""
+    too) -- through every candidate search: the grid walks over compact and wide tables (LDS and global memory), range
+    tables, box hierarchy, wave votes; all equal to the flat scan, and sampled rows to the CPU checker."""
     rng = np.random.default_rng(fuzz_seed)
     for case in range(7):
         n = int(rng.choice([20, 70, 300, 900, 2500]))
@@ -82,9 +83,7 @@ def test_random_geometry_every_candidate_search_equals_the_flat_scan(rtmi, rtche
         st = sc.count(rtmi.Opts(seed=case))
         flat = sc.render(rtmi.Opts(seed=case, variant=16))
         what = f"case {case}: n {n} sheet {sheet} half {half:.1f} inside {inside} {w}x{h}x{spp} mode {st.cull_mode} windows {st.cull_windows}"
-        variants = [0, 1, 40, 64, 104, 32, 128, 136]
-        if st.cull_windows <= 1:
-            variants.append(4)
+        variants = [0, 1, 2, 6, 40, 36, 44, 64, 32, 128]  # (those that do not fit the scene are refused: status 6)
         for v in variants:
             try:
                 img = sc.render(rtmi.Opts(seed=case, variant=v))

@@ -127,20 +127,34 @@ def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
     assert np.abs(acc - whole).max() <= 13 * 2.0 ** -24 * max(1.0, acc.max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 8, 16, 17, 19, 24, 32, 40, 64, 104, 128, 136])
+COMPACT_VARIANTS = (1, 2, 6, 40)   # the compact grid tables: sphere-only scenes that fit LDS
+WIDE_VARIANTS = (36, 44)           # the wide grid tables: every other scene
+
+
+@pytest.mark.parametrize("variant", [0, 2, 6, 36, 44, 1, 40, 16, 17, 24, 32, 64, 128])
 def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir, variant):
-    """variant bit 0: strict one-lane-per-pixel ownership instead of the tile sample pool;
-    bit 1: unbatched sphere loop; bit 3: sphere table read through the scalar cache instead of
-    LDS; bit 4: no AABB cluster culling (the reference's linear scan); bit 5: wave-level cluster votes;
-    bit 6: candidate clusters through the box hierarchy, bit 7: through the range tables, instead of the
-    uniform-grid walk (0, 1, 40).  Same bits as the checker in every combination."""
-    for name, w, h, spp in (("rtiow", 72, 40, 6), ("mixed_emissive", 50, 30, 5)):
+    """The product kernels (0 -> 2 / 6 / 36 / 44: uniform-grid walk over compact or wide tables, in LDS or global memory) and
+    the measurement variants of the default build (1 strict one-lane-per-pixel ownership, 40 compact tables in global
+    memory, 16 / 17 / 24 the reference's linear scan, 32 wave votes, 64 box hierarchy, 128 range tables): same bits as the
+    checker in every combination; a variant whose table format the scene does not have is refused."""
+    for name, w, h, spp, sphere_only in (("rtiow", 72, 40, 6, True), ("mixed_emissive", 50, 30, 5, False)):
         sc = _scene(rtmi, scenes_dir, golden_dir, name)
         sc.override(width=w, height=h, spp=spp)
+        if variant in (WIDE_VARIANTS if sphere_only else COMPACT_VARIANTS):
+            with pytest.raises(rtmi.RtmiError) as e:
+                sc.render(rtmi.Opts(variant=variant))
+            assert e.value.status == 6
+            continue
         _assert_same(rtmi, rtcheck, sc, variant=variant)
         _assert_same(rtmi, rtcheck, sc, variant=variant, spp_chunk=2)
+        st = rtmi.Stats()
+        sc.render(rtmi.Opts(seed=SEED, variant=variant), st)
+        assert st.kernel_variant == (variant if variant else (2 if sphere_only else 36))
     with pytest.raises(rtmi.RtmiError, match="variant"):
         sc.render(rtmi.Opts(variant=9))
+    for gone in (4, 8, 19, 104, 136):  # measurement variants of earlier rounds (DESIGN.md keeps their numbers)
+        with pytest.raises(rtmi.RtmiError, match="variant"):
+            sc.render(rtmi.Opts(variant=gone))
 
 
 def test_exact_event_counters(rtmi, rtcheck, scenes_dir, golden_dir):
@@ -269,11 +283,14 @@ def test_many_spheres_above_64k_lds(rtmi, rtcheck):
     sc.camera((0, 2, 12), (0, 0, 0), (0, 1, 0), 40.0)
     rng = np.random.default_rng(5)
     mats = [sc.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(8)] + [sc.metal((0.8, 0.8, 0.8), 0.1), sc.dielectric(1.5)]
-    for i in range(3000):
+    for i in range(5000):
         sc.sphere(rng.uniform(-6, 6, 3), float(rng.uniform(0.05, 0.2)), mats[i % len(mats)])
-    _assert_same(rtmi, rtcheck, sc)              # default: global-memory tables at this size
-    _assert_same(rtmi, rtcheck, sc, variant=32)  # tables in LDS (about 120 KB with the grid tables in front of the boxes: the raised dynamic-LDS limit)
-    _assert_same(rtmi, rtcheck, sc, variant=64)  # per-lane lists through the box hierarchy (global tables at this size)
+    st = rtmi.Stats()
+    sc.render(rtmi.Opts(seed=SEED), st)
+    assert st.kernel_variant == 44               # default: wide tables in global memory at this size
+    _assert_same(rtmi, rtcheck, sc)
+    _assert_same(rtmi, rtcheck, sc, variant=32)  # tables in LDS (105 KB: the raised dynamic-LDS limit)
+    _assert_same(rtmi, rtcheck, sc, variant=64)  # per-lane lists through the box hierarchy, LDS as well
 
 
 def test_full_frame_properties(rtmi, rtcheck):
@@ -323,46 +340,36 @@ def test_axis_parallel_bounce_is_not_culled(rtmi, rtcheck):
     assert len(queries) == 1 and queries[0][3] == 0.0 and queries[0][7] == 1.0  # d.x == 0 exactly, and the ray hits
     assert abs(queries[0][6] - 0.9) < 1e-3                                      # the sphere at (1000, 0, 0), t = 4.5 / 5
     imgs = {}
-    for variant in (0, 1, 4, 32, 64, 128, 16):
+    # (1000 units from the coordinate origin the lists' growth spans several cells: more than 63 entries per cell, so this
+    #  scene gets the wide tables)
+    for variant in (0, 36, 44, 32, 64, 128, 16):
         imgs[variant] = _assert_same(rtmi, rtcheck, sc, variant=variant)
         assert np.all(imgs[variant][4, 4] == np.float32([4.0, 8.0, 12.0]))  # 4 spp x the lattice centre's light (1, 2, 3)
-    for variant in (0, 1, 4, 32, 64, 128):
+    for variant in (0, 36, 44, 32, 64, 128):
         assert np.array_equal(imgs[variant], imgs[16])
 
 
-def test_both_cluster_sizes_equal_the_checker(rtmi, rtcheck, monkeypatch):
-    """The packer clusters spheres by 8 (both kernels are compiled; round 1's box hierarchy preferred 16 on sheets);
-    RTMI_CLUSTER forces either size, which must not change a bit."""
-    for forced in ("8", "16"):
-        monkeypatch.setenv("RTMI_CLUSTER", forced)
-        sc = rtmi.Scene.rtiow(5, 120, 68, 5, 50)   # a sheet
-        st = sc.count(rtmi.Opts(seed=SEED))
-        assert st.cull_cluster_size == int(forced)
-        _assert_same(rtmi, rtcheck, sc)
-        _assert_same(rtmi, rtcheck, sc, variant=32)
-        _assert_same(rtmi, rtcheck, sc, variant=64)
-        _assert_same(rtmi, rtcheck, sc, variant=128)
-        vol = rtmi.Scene.new(64, 40, 3, 10)        # a volume
-        vol.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
-        vol.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
-        rng = np.random.default_rng(21)
-        mats = [vol.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(4)] + [vol.metal((0.8, 0.8, 0.8), 0.1), vol.dielectric(1.5)]
-        for i in range(300):
-            vol.sphere(rng.uniform(-4, 4, 3), float(rng.uniform(0.05, 0.3)), mats[i % len(mats)])
-        assert vol.count(rtmi.Opts(seed=SEED)).cull_cluster_size == int(forced)
-        _assert_same(rtmi, rtcheck, vol)
-        _assert_same(rtmi, rtcheck, vol, variant=40)
-        _assert_same(rtmi, rtcheck, vol, variant=104)
-        _assert_same(rtmi, rtcheck, vol, variant=136)
-    monkeypatch.delenv("RTMI_CLUSTER")
-    assert rtmi.Scene.rtiow(5, 32, 18, 1, 5).count(rtmi.Opts()).cull_cluster_size == 8
-    vol2 = rtmi.Scene.new(16, 16, 1, 3)
-    vol2.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
-    m = vol2.lambertian((0.5, 0.5, 0.5))
-    rng = np.random.default_rng(2)
-    for i in range(100):
-        vol2.sphere(rng.uniform(-4, 4, 3), 0.2, m)
-    assert vol2.count(rtmi.Opts()).cull_cluster_size == 8
+def test_cluster_searches_on_a_sheet_and_a_volume(rtmi, rtcheck):
+    """The measurement variants that search the sphere clusters (8 per cluster; round 1 also built 16) on both kinds of
+    scene: wave votes, box hierarchy, range tables; the compact grid through global memory."""
+    sc = rtmi.Scene.rtiow(5, 120, 68, 5, 50)   # a sheet
+    st = sc.count(rtmi.Opts(seed=SEED))
+    assert st.cull_cluster_size == 8 and st.kernel_variant == 6 and st.grid_sheet == 1
+    _assert_same(rtmi, rtcheck, sc)
+    for v in (32, 64, 128, 40):
+        _assert_same(rtmi, rtcheck, sc, variant=v)
+    vol = rtmi.Scene.new(64, 40, 3, 10)        # a volume
+    vol.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
+    vol.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
+    rng = np.random.default_rng(21)
+    mats = [vol.lambertian(rng.uniform(0.2, 0.9, 3)) for _ in range(4)] + [vol.metal((0.8, 0.8, 0.8), 0.1), vol.dielectric(1.5)]
+    for i in range(300):
+        vol.sphere(rng.uniform(-4, 4, 3), float(rng.uniform(0.05, 0.3)), mats[i % len(mats)])
+    st = vol.count(rtmi.Opts(seed=SEED))
+    assert st.cull_cluster_size == 8 and st.kernel_variant == 6 and st.grid_sheet == 0
+    _assert_same(rtmi, rtcheck, vol)
+    for v in (32, 64, 128, 40, 1):
+        _assert_same(rtmi, rtcheck, vol, variant=v)
 
 
 def test_culling_is_conservative_for_fp32_noise(rtmi, rtcheck):
@@ -444,17 +451,16 @@ def test_big_sheet_uses_range_tables_over_many_windows(rtmi, rtcheck):
         r = float(rng.uniform(0.05, 0.15))
         sc.sphere((float(rng.uniform(-20, 20)), r, float(rng.uniform(-20, 20))), r, mats[i % len(mats)])
     st = sc.count(rtmi.Opts(seed=SEED))
-    assert st.cull_mode == 5 and st.lane_clusters > 0 and st.lane_groups > 0
-    st = sc.count(rtmi.Opts(seed=SEED, variant=136))
+    assert st.cull_mode == 7 and st.kernel_variant == 44 and st.lane_clusters > 0 and st.lane_groups > 0
+    st = sc.count(rtmi.Opts(seed=SEED, variant=128))
     assert st.cull_mode == 3 and st.cull_windows == 6 and st.cull_clusters == 375 and st.lane_cands >= st.lane_clusters > 0
     img = _assert_same(rtmi, rtcheck, sc)
     assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
-    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=1)))    # grid tables in LDS
-    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=136)))
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=36)))   # the wide grid tables in LDS
     assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=128)))  # range tables in LDS (90 KB per workgroup)
     assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=64)))   # the box hierarchy on the same clusters
-    with pytest.raises(rtmi.RtmiError, match="one window"):
-        sc.render(rtmi.Opts(seed=SEED, variant=4))
+    with pytest.raises(rtmi.RtmiError, match="compact"):
+        sc.render(rtmi.Opts(seed=SEED, variant=1))  # no compact tables at this size
 
 
 def _cloud(rtmi, n, half, seed, w=64, h=40, spp=3, depth=12, r=(0.05, 0.25)):
@@ -477,47 +483,66 @@ def test_grid_list_tiers_and_the_scan_beyond_them(rtmi, rtcheck):
         sc.xy_rect(-300.0, 300.0, -300.0, 300.0, mirror_z, sc.metal((0.95, 0.95, 0.95), 0.0))
         sc.camera((0.0, 2.0, 14.0), (0.0, 0.0, 0.0), (0, 1, 0), 40.0)
         st = sc.count(rtmi.Opts(seed=SEED))
-        assert st.cull_mode == 5 and st.lane_groups > 0
+        assert st.cull_mode == 7 and st.kernel_variant == 36 and st.lane_groups > 0  # (the mirror makes it a wide-table scene)
         if far_tier:
             assert st.group_maxpop > 0, "no lane walked the far tier"
         if beyond:
             assert st.query_maxpop > 0, "no lane scanned from beyond the lists' reach"
         img = _assert_same(rtmi, rtcheck, sc)
         assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
-        assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=40)))
-        assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=1)))
+        assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=44)))
+        # the same with a mirror SPHERE of radius 1000 (always tested: no entry of the lists): a compact-table scene
+        sph, _ = _cloud(rtmi, 300, 3.0, 31, w=80, h=50, spp=4)
+        sph.sphere((0.0, 0.0, mirror_z - 1000.0), 1000.0, sph.metal((0.95, 0.95, 0.95), 0.0))
+        sph.camera((0.0, 2.0, 14.0), (0.0, 0.0, 0.0), (0, 1, 0), 40.0)
+        st = sph.count(rtmi.Opts(seed=SEED))
+        assert st.cull_mode == 5 and st.kernel_variant == 6 and st.lane_groups > 0
+        assert (st.group_maxpop > 0) if far_tier else (st.query_maxpop > 0)
+        img = _assert_same(rtmi, rtcheck, sph)
+        for v in (16, 40, 1):
+            assert np.array_equal(img, sph.render(rtmi.Opts(seed=SEED, variant=v)))
 
 
-def test_scenes_without_a_grid_fall_back_to_the_cluster_search(rtmi, rtcheck):
-    """More than 63 spheres listed in one cell (a clump) leaves the scene without a grid: the default is then the range
-    tables (sheet) or the box hierarchy (volume), and an explicit grid variant is refused."""
+def test_clumps_keep_their_grid(rtmi, rtcheck):
+    """More than 63 spheres listed in one cell (a clump) is more than the compact tables hold: the scene gets the wide
+    tables (1023 per cell).  A clump beyond those too is taken out of the lists and tested for every query -- in the limit
+    the reference's scan.  (Until round 3 such scenes fell back to the cluster searches.)"""
     sc, mats = _cloud(rtmi, 200, 4.0, 41)
     rng = np.random.default_rng(42)
     for i in range(90):  # the clump
         sc.sphere(tuple(np.array([1.0, 1.0, 1.0]) + rng.uniform(-0.02, 0.02, 3)), 0.1, mats[i % len(mats)])
     sc.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
     st = sc.count(rtmi.Opts(seed=SEED))
-    assert st.cull_mode in (2, 3)
+    assert st.cull_mode == 7 and st.kernel_variant == 36
     img = _assert_same(rtmi, rtcheck, sc)
     assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
-    with pytest.raises(rtmi.RtmiError, match="grid"):
+    with pytest.raises(rtmi.RtmiError, match="compact"):
         sc.render(rtmi.Opts(seed=SEED, variant=1))
+    big, mats = _cloud(rtmi, 100, 4.0, 43, w=32, h=20, spp=2, depth=4)
+    for i in range(1100):  # beyond the wide tables' 1023 per cell
+        big.sphere(tuple(np.array([-1.0, 0.5, 1.0]) + rng.uniform(-0.01, 0.01, 3)), 0.05, mats[i % len(mats)])
+    big.camera((0, 2, 14), (0, 0, 0), (0, 1, 0), 40.0)
+    st = big.count(rtmi.Opts(seed=SEED))
+    assert st.cull_mode == 7 and st.cull_prefix >= 1100  # the clump's members are tested for every query
+    img = _assert_same(rtmi, rtcheck, big)
+    assert np.array_equal(img, big.render(rtmi.Opts(seed=SEED, variant=16)))
 
 
-def test_sheet_walk_equals_the_3d_walk_and_the_flat_scan(rtmi, rtcheck, monkeypatch):
+def test_sheet_walk_equals_the_3d_walk_and_the_flat_scan(rtmi, rtcheck):
     """A grid that is one cell high (RTIOW's spheres on the ground) is walked along x and z only (variant 2, what
-    variant 0 picks by itself there).  Same cells, same tests, same bytes as the 3-D walk (RTMI_NO_SHEET=1) and as the
+    variant 0 picks by itself there).  Same cells, same tests, same bytes as the 3-D walk (variant 6) and as the
     linear scan; a volume has no such grid and refuses variant 2."""
     sc = rtmi.Scene.rtiow(11, 160, 90, 6, 50)
     flat = sc.render(rtmi.Opts(seed=SEED, variant=16))
     auto = _assert_same(rtmi, rtcheck, sc, variant=0)
     sheet = sc.render(rtmi.Opts(seed=SEED, variant=2))
     assert np.array_equal(auto, flat) and np.array_equal(sheet, flat)
+    assert np.array_equal(sc.render(rtmi.Opts(seed=SEED, variant=6)), flat)
     # a camera inside the sheet, looking along it: long walks through many cells, rays that leave through the top
     low = rtmi.Scene.rtiow(11, 160, 90, 4, 50)
     low.camera((0.3, 0.25, 0.2), (8.0, 0.3, 6.0), (0, 1, 0), 70.0, 160 / 90, 0.05, 4.0)
     assert np.array_equal(low.render(rtmi.Opts(seed=3, variant=2)), low.render(rtmi.Opts(seed=3, variant=16)))
-    assert np.array_equal(low.render(rtmi.Opts(seed=3, variant=2)), low.render(rtmi.Opts(seed=3, variant=1)))  # (variant 1 walks in 3-D)
+    assert np.array_equal(low.render(rtmi.Opts(seed=3, variant=2)), low.render(rtmi.Opts(seed=3, variant=6)))  # (the 3-D walk)
     vol = rtmi.Scene.new(64, 40, 3, 10)
     vol.set_background((0.5, 0.7, 1.0), sky_gradient=True, defocus_blur=False)
     vol.camera((0, 0, 12), (0, 0, 0), (0, 1, 0), 40.0, 1.6, 0.0, 12.0)
@@ -531,10 +556,10 @@ def test_sheet_walk_equals_the_3d_walk_and_the_flat_scan(rtmi, rtcheck, monkeypa
     assert np.array_equal(vol.render(rtmi.Opts(seed=1)), vol.render(rtmi.Opts(seed=1, variant=16)))
 
 
-def test_wide_grid_tables_for_65536_spheres_and_more(rtmi):
+def test_wide_grid_tables_for_65536_spheres_and_more(rtmi, rtcheck):
     """Scenes with 65536 sphere slots or more get the WIDE grid tables (32-bit list entries, two words per cell, up to 1023
-    cells per axis) and their own kernel instance (variant 44, global memory); before, such scenes fell back to the box
-    hierarchy.  A volume and a sheet (more than 255 cells along two axes) against the linear scan and the cluster search."""
+    cells per axis).  A volume and a sheet (more than 255 cells along two axes) against the linear scan, and two row bands
+    of each against the CPU checker."""
     rng = np.random.default_rng(17)
     vol = rtmi.Scene.new(48, 32, 2, 6)
     vol.set_background((0.5, 0.7, 1.0), sky_gradient=True, defocus_blur=False)
@@ -543,11 +568,15 @@ def test_wide_grid_tables_for_65536_spheres_and_more(rtmi):
     c = rng.uniform(-8, 8, (70000, 3)).astype(np.float32)
     for i in range(len(c)):
         vol.sphere((float(c[i, 0]), float(c[i, 1]), float(c[i, 2])), 0.06, mats[i % 3])
-    auto = vol.render(rtmi.Opts(seed=5))  # variant 0 picks 44 here: 1, 2 and 40 (the 16-bit tables) are refused below
-    assert np.array_equal(auto, vol.render(rtmi.Opts(seed=5, variant=44)))
+    st = rtmi.Stats()
+    auto = vol.render(rtmi.Opts(seed=5), st)
+    assert st.kernel_variant == 44
     assert np.array_equal(auto, vol.render(rtmi.Opts(seed=5, variant=24)))   # the linear scan (tables in global memory)
-    assert np.array_equal(auto, vol.render(rtmi.Opts(seed=5, variant=104)))  # box hierarchy, global tables
-    for bad in (1, 2, 40):
+    osc = rtcheck.OracleScene(vol)
+    for y in (3, 17):
+        ref, _ = rtcheck.oracle_render(osc, seed=5, rows=(y, y + 2))
+        assert np.array_equal(auto[y:y + 2], ref[y:y + 2])
+    for bad in (1, 2, 6, 40):
         with pytest.raises(rtmi.RtmiError):
             vol.render(rtmi.Opts(seed=5, variant=bad))
     sheet = rtmi.Scene.new(48, 32, 2, 6)
@@ -560,8 +589,12 @@ def test_wide_grid_tables_for_65536_spheres_and_more(rtmi):
     for a in range(n):
         for b in range(n):
             sheet.sphere((float(0.1 * (a - n / 2) + j[a, b, 0]), 0.03, float(0.1 * (b - n / 2) + j[a, b, 1])), 0.03, m[(a + b) % 2])
-    img = sheet.render(rtmi.Opts(seed=9))
-    assert np.array_equal(img, sheet.render(rtmi.Opts(seed=9, variant=44)))
+    img = sheet.render(rtmi.Opts(seed=9), st)
+    assert st.kernel_variant == 44
     assert np.array_equal(img, sheet.render(rtmi.Opts(seed=9, variant=24)))
-    with pytest.raises(rtmi.RtmiError):  # and a small scene has no wide tables
+    osc = rtcheck.OracleScene(sheet)
+    for y in (2, 20):
+        ref, _ = rtcheck.oracle_render(osc, seed=9, rows=(y, y + 2))
+        assert np.array_equal(img[y:y + 2], ref[y:y + 2])
+    with pytest.raises(rtmi.RtmiError):  # and a small sphere-only scene has no wide tables
         rtmi.Scene.rtiow(3, 32, 18, 1, 5).render(rtmi.Opts(seed=1, variant=44))

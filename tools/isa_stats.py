@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static picture of ONE render_kernel instance (no GPU needed): registers, scratch, instruction mix.
-usage: tools/isa_stats.py [--inst "false,true,true,false,6,8,false,true"] [--waves 7] [--keep out.s] [-- extra hipcc flags]
+usage: tools/isa_stats.py [--inst "false,true,false,6,false,true"] [--waves 7] [--keep out.s] [-- extra hipcc flags]
 The default instance is the headline kernel (sphere-only x-z grid walk, variant 0 -> 2 on RTIOW)."""
 import argparse, collections, os, re, subprocess, sys, tempfile
 
@@ -10,7 +10,7 @@ SRC = os.path.join(ROOT, "ray-tracing-in-cuda_amd", "csrc", "render_kernel.hip")
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--inst", default="false,true,true,false,6,8,false,true")
+    ap.add_argument("--inst", default="false,true,false,6,false,true")
     ap.add_argument("--waves", type=int, default=7)
     ap.add_argument("--keep", default=None)
     ap.add_argument("extra", nargs="*")
