@@ -255,12 +255,14 @@ typedef struct rt_opts {
                                6  uniform-grid walk, compact tables in LDS (sphere-only scenes that fit LDS)
                               36  uniform-grid walk over the wide tables in LDS: every primitive type is listed in the cells
                               44  the same with the tables in global memory (scenes too large for LDS: no size limit)
+                              16  no culling: the reference's linear hittable_list scan (a handful of primitives of several
+                                  types; also the definition the other kernels' images are held to)
                              (rt_stats.kernel_variant reports the choice).  Libraries built with RTMI_ABLATIONS (the default
                              build: rt_has_ablations()) also carry measurement variants with the same image, bit for bit:
                                1 = 6 with strict one-lane-per-pixel ownership, 40 = 6 with its tables in global memory,
-                              16 = no culling (the reference's linear hittable_list scan), 17 = 16 with strict ownership,
-                              24 = 16 with the tables in global memory, 32 = wave-level cluster votes, 64 = per-lane cluster
-                              lists through a two-level box hierarchy, 128 = per-lane cluster lists through range tables */
+                              17 = 16 with strict ownership, 24 = 16 with the tables in global memory, 32 = wave-level
+                              cluster votes, 64 = per-lane cluster lists through a two-level box hierarchy, 128 = per-lane
+                              cluster lists through range tables */
 } rt_opts;
 
 typedef struct rt_stats {
@@ -356,6 +358,8 @@ int rt_render_hip_count(const rt_scene *s, const rt_opts *o, float *rgb_sum, rt_
 int rt_render_hip_accumulate(const rt_scene *s, const rt_opts *o, int64_t *acc, float *rgb_sum,
                              rt_stats *stats);
 
+/* fractional bits of the exact pixel sums (a file or buffer of sums written in another scale cannot be continued) */
+#define RT_ACC_FIX_BITS 24
 /* fp32 framebuffer values of exact sums: rgb_sum[i] = (float)(acc[i] * 2^-24), the conversion the
  * render path itself applies once per launch. */
 void rt_acc_to_rgb(const int64_t *acc, float *rgb_sum, size_t n_values);
@@ -400,7 +404,7 @@ size_t rt_struct_size(int which);
 int rt_device_count(void);
 /* 1 if this library carries the measurement variants of rt_opts.variant and the counting kernels of rt_render_hip_count
  * (the default build; `make ABLATIONS=0` builds the six product kernels alone: same ABI, rt_render_hip_count then
- * fails with RT_ERR_LIMIT and rt_opts.variant accepts 0, 2, 6, 36, 44) */
+ * fails with RT_ERR_LIMIT and rt_opts.variant accepts 0, 2, 6, 16, 36, 44) */
 int rt_has_ablations(void);
 /* Philox4x32-10 block (seeds every (pixel, sample) stream), for known-answer tests */
 void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

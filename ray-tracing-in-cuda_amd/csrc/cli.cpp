@@ -23,11 +23,11 @@
 
 // exact pixel sums on disk: 40-byte header + int64[height][width][3], little endian
 struct AccHeader {
-    char magic[8];  // "RTMIACC1"
+    char magic[8];  // "RTMIACC2" (version 1 held sums in units of 2^-32)
     int32_t width, height;
     int64_t samples_done;  // samples [0, samples_done) are in the sums
     uint64_t seed;
-    int64_t reserved;
+    int64_t fix_bits;      // fractional bits of the sums (RT_ACC_FIX_BITS): a file in another scale is refused
 };
 static_assert(sizeof(AccHeader) == 40, "accumulator file header");
 
@@ -149,8 +149,13 @@ int main(int argc, char **argv) {
         if (!acc_in.empty()) {
             FILE *fp = fopen(acc_in.c_str(), "rb");
             AccHeader h;
-            if (!fp || fread(&h, sizeof h, 1, fp) != 1 || memcmp(h.magic, "RTMIACC1", 8) != 0) {
+            if (!fp || fread(&h, sizeof h, 1, fp) != 1 || memcmp(h.magic, "RTMIACC", 7) != 0) {
                 fprintf(stderr, "rtmi: %s is not an accumulator file\n", acc_in.c_str());
+                return 1;
+            }
+            if (h.magic[7] != '2' || h.fix_bits != RT_ACC_FIX_BITS) {
+                fprintf(stderr, "rtmi: %s holds pixel sums in another fixed-point scale (format '%c', %lld fractional bits; this build: "
+                        "'2', %d): it cannot be continued\n", acc_in.c_str(), h.magic[7], (long long)h.fix_bits, RT_ACC_FIX_BITS);
                 return 1;
             }
             if (h.width != info.width || h.height != info.height || h.seed != seed) {
@@ -179,7 +184,7 @@ int main(int argc, char **argv) {
         rc = rt_render_hip_accumulate(sc, &o, acc.data(), img.data(), &st);
         total_spp = (int)(spp_begin + info.samples_per_pixel);
         if (rc == RT_OK && !acc_out.empty()) {
-            AccHeader h = {{'R', 'T', 'M', 'I', 'A', 'C', 'C', '1'}, info.width, info.height, total_spp, seed, 0};
+            AccHeader h = {{'R', 'T', 'M', 'I', 'A', 'C', 'C', '2'}, info.width, info.height, total_spp, seed, RT_ACC_FIX_BITS};
             FILE *fp = fopen(acc_out.c_str(), "wb");
             if (!fp || fwrite(&h, sizeof h, 1, fp) != 1 ||
                 fwrite(acc.data(), sizeof(int64_t), acc.size(), fp) != acc.size() || fclose(fp) != 0) {

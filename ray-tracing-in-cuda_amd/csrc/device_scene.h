@@ -48,7 +48,7 @@
 #endif
 
 // Pixel sums: signed 64-bit fixed point with RT_FIX_BITS fractional bits (include/rtmi.h, rt_render_hip_accumulate)
-#define RT_FIX_BITS 24
+#define RT_FIX_BITS 24  /* = RT_ACC_FIX_BITS of include/rtmi.h (static_assert in render_kernel.hip) */
 #define RT_FIX_CLAMP 65536.0f
 #define RT_MAX_SAMPLES_PER_PIXEL (1 << 23)
 

@@ -63,7 +63,9 @@ struct Huffman {  // canonical code, decoded bit by bit (textures are small)
     }
 };
 
-inline bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err) {
+// max_out: the most the stream may expand to (the caller knows the image size): a crafted stream of a few KB would otherwise
+// grow to gigabytes (deflate reaches about 1000 : 1) before any size check
+inline bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err, size_t max_out) {
     static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
     static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -87,6 +89,10 @@ inline bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std
             const unsigned len = br.p[0] | br.p[1] << 8, nlen = br.p[2] | br.p[3] << 8;
             br.p += 4;
             if ((len ^ 0xffffu) != nlen || (size_t)(br.end - br.p) < len) break;
+            if (out.size() + len > max_out) {
+                err = "zlib stream expands beyond the image it belongs to";
+                return false;
+            }
             out.insert(out.end(), br.p, br.p + len);
             br.p += len;
         } else if (type == 1 || type == 2) {
@@ -142,6 +148,10 @@ inline bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std
             for (;;) {
                 const int sym = lit.decode(br);
                 if (sym < 0) break;
+                if (sym < 256 && out.size() >= max_out) {
+                    err = "zlib stream expands beyond the image it belongs to";
+                    return false;
+                }
                 if (sym < 256) out.push_back((uint8_t)sym);
                 else if (sym == 256) {
                     done = true;
@@ -154,6 +164,10 @@ inline bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std
                     if (ds < 0 || ds >= 30) break;
                     const size_t d = dist_base[ds] + br.bits(dist_extra[ds]);
                     if (!br.ok || d > out.size()) break;
+                    if (out.size() + (size_t)len > max_out) {
+                        err = "zlib stream expands beyond the image it belongs to";
+                        return false;
+                    }
                     const size_t from = out.size() - d;
                     for (int k = 0; k < len; ++k) out.push_back(out[from + k]);
                 }
@@ -214,8 +228,8 @@ inline bool read(const std::vector<uint8_t> &file, int &rows, int &cols, std::ve
         return false;
     }
     std::vector<uint8_t> raw;
-    if (!inflate(idat.data(), idat.size(), raw, err)) return false;
     const size_t stride = (size_t)w * ch;
+    if (!inflate(idat.data(), idat.size(), raw, err, (stride + 1) * h)) return false;
     if (raw.size() < (stride + 1) * h) {
         err = "PNG image data too short";
         return false;

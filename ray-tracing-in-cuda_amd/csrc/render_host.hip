@@ -1106,14 +1106,17 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     };
     static const size_t global_threshold = (size_t)knob("RTMI_GLOBAL_TABLE_BYTES", (double)kLdsTableBytes);
     const bool sphere_only = P.nr + P.nc + P.nt == 0 && !ext;
-    auto pick = [&]() -> unsigned {  // what variant 0 stands for in this scene
+    auto pick = [&](bool counting) -> unsigned {  // what variant 0 stands for in this scene
         if (!P.grid_wide) return P.grid_sheet ? 2u : 6u;
+        // a handful of primitives of several types, none of them listed in a grid: the plain scan is the same search without
+        // the per-query set-up (sample_scene.json: 54 against 79 ms)
+        if (P.grid_cells == 0 && P.ncl == 0 && !counting && hot_bytes_of(16) <= global_threshold) return 16u;
         return hot_bytes_of(36) <= global_threshold ? 36u : 44u;
     };
-    if (variant == 0) variant = pick();
+    if (variant == 0) variant = pick(count);
     // the counting kernels exist for the grid walks (3-D) and two ablation searches: anything else is counted by the kernel
     // variant 0 would run (reported in stats->kernel_variant / cull_mode)
-    if (count && !variant_has_count(variant)) variant = (variant == 2) ? 6u : pick();
+    if (count && !variant_has_count(variant)) variant = (variant == 2) ? 6u : pick(true);
     if (count && variant == 2) variant = 6;
     const int mode = variant_cull_mode(variant);
     if ((mode == 5 || mode == 6) && P.grid_wide) {

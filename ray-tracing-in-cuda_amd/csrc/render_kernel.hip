@@ -85,6 +85,7 @@
 namespace rtmi {
 
 static constexpr float kTMin = 0.001f;  // main.cu:45 / main.cpp:22
+static_assert(RT_FIX_BITS == RT_ACC_FIX_BITS, "the kernel's pixel sums and the ABI's scale");
 
 // ---------------------------------------------------------------- RNG
 struct LaneRng {
@@ -1559,37 +1560,39 @@ template __global__ void render_kernel<RT_ISA_ONLY>(const RenderParams, const fl
                                                     unsigned int *__restrict__, DevCounters *__restrict__);
 #else
 // ---------------------------------------------------------------- launchers used by render_host.hip
-// X(variant id, POOL, SCALAR, CULL, SPH).  The host resolves variant 0 to one of the four PRODUCT instances:
+// X(variant id, POOL, SCALAR, CULL, SPH).  The host resolves variant 0 to one of the five PRODUCT instances:
 //    2  compact grid one cell high, tables in LDS (RTIOW)         6  compact grid, 3-D walk, tables in LDS (sphere-only scenes)
 //   36  wide grid tables in LDS (scenes with other primitives)   44  wide grid tables in global memory (large scenes)
-// and the wide ones also exist with EXT (triangles, image textures): six render_kernel instances in a product build
+//   16  no culling -- the reference's linear hittable_list scan: what a scene of a handful of primitives of several types runs
+//       (nothing is listed in a grid there; sample_scene.json 54 ms against 79 ms for 36 with its empty grid), and the
+//       definition every other kernel's image is held to
+// and 36, 44 and 16 also exist with EXT (triangles, image textures): eight render_kernel instances in a product build
 // (make ABLATIONS=0).  The default build (RTMI_ABLATIONS=1: tests, bench.py) adds the measurement variants -- same image, bit for
 // bit -- and the counting kernels:
 //    1  variant 6 with strict one-lane-per-pixel ownership       40  variant 6 with its tables in global memory
-//   16  no culling: the reference's linear hittable_list scan    17  ... with strict ownership       24  ... tables in global memory
+//   17  variant 16 with strict ownership                         24  variant 16 with its tables in global memory
 //   32  wave-level cluster votes      64  per-lane cluster lists through the two-level box hierarchy (round 1's default)
 //  128  per-lane cluster lists through the range tables (first half of round 2)
 #define RT_PRODUCT_TABLE(X)          \
     X(2, true, false, 6, true)       \
     X(6, true, false, 5, true)       \
     X(36, true, false, 7, false)     \
-    X(44, true, true, 7, false)
+    X(44, true, true, 7, false)      \
+    X(16, true, false, 0, false)
 #define RT_PRODUCT_EXT_TABLE(X)      \
     X(36, true, false, 7, false)     \
-    X(44, true, true, 7, false)
+    X(44, true, true, 7, false)      \
+    X(16, true, false, 0, false)
 #if RTMI_ABLATIONS
 #define RT_ABLATION_TABLE(X)         \
     X(1, false, false, 5, true)      \
     X(40, true, true, 5, true)       \
-    X(16, true, false, 0, false)     \
     X(17, false, false, 0, false)    \
     X(24, true, true, 0, false)      \
     X(32, true, false, 1, false)     \
     X(64, true, false, 2, false)     \
     X(128, true, false, 3, false)
-#define RT_ABLATION_EXT_TABLE(X)     \
-    X(16, true, false, 0, false)     \
-    X(24, true, true, 0, false)
+#define RT_ABLATION_EXT_TABLE(X) X(24, true, true, 0, false)
 // counting kernels (rt_render_hip_count): X(variant, SCALAR, CULL, EXT, SPH)
 #define RT_COUNT_TABLE(X)            \
     X(6, false, 5, false, true)      \

@@ -149,7 +149,7 @@ def test_kernel_variants_are_bit_identical(rtmi, rtcheck, scenes_dir, golden_dir
         _assert_same(rtmi, rtcheck, sc, variant=variant, spp_chunk=2)
         st = rtmi.Stats()
         sc.render(rtmi.Opts(seed=SEED, variant=variant), st)
-        assert st.kernel_variant == (variant if variant else (2 if sphere_only else 36))
+        assert st.kernel_variant == (variant if variant else (2 if sphere_only else 16))  # (12 primitives: nothing to list in a grid)
     with pytest.raises(rtmi.RtmiError, match="variant"):
         sc.render(rtmi.Opts(variant=9))
     for gone in (4, 8, 19, 104, 136):  # measurement variants of earlier rounds (DESIGN.md keeps their numbers)

@@ -38,14 +38,23 @@ def test_cli_checks_the_accumulator_file_before_rendering(tmp_path):
     bad.write_bytes(b"not an accumulator")
     r = _run(["--rtiow", "-w", "16", "-h", "8", "-spp", "2", "--acc-in", str(bad), "-o", str(tmp_path / "o.ppm")])
     assert r.returncode == 1 and "not an accumulator file" in r.stderr
+    # a file of the earlier format (sums in units of 2^-32): refused, not continued 256 x too bright
+    old = tmp_path / "old.bin"
+    old.write_bytes(struct.pack("<8siiqQq", b"RTMIACC1", 16, 8, 4, 2023, 0) + bytes(16 * 8 * 3 * 8))
+    r = _run(["--rtiow", "-w", "16", "-h", "8", "-spp", "2", "--acc-in", str(old), "-o", str(tmp_path / "o.ppm")])
+    assert r.returncode == 1 and "fixed-point scale" in r.stderr
+    other = tmp_path / "other.bin"
+    other.write_bytes(struct.pack("<8siiqQq", b"RTMIACC2", 16, 8, 4, 2023, 32) + bytes(16 * 8 * 3 * 8))
+    r = _run(["--rtiow", "-w", "16", "-h", "8", "-spp", "2", "--acc-in", str(other), "-o", str(tmp_path / "o.ppm")])
+    assert r.returncode == 1 and "fixed-point scale" in r.stderr
     # right magic, wrong frame size
-    hdr = struct.pack("<8siiqQq", b"RTMIACC1", 32, 8, 4, 2023, 0)
+    hdr = struct.pack("<8siiqQq", b"RTMIACC2", 32, 8, 4, 2023, 24)
     wrong = tmp_path / "wrong.bin"
     wrong.write_bytes(hdr + bytes(32 * 8 * 3 * 8))
     r = _run(["--rtiow", "-w", "16", "-h", "8", "-spp", "2", "--acc-in", str(wrong), "-o", str(tmp_path / "o.ppm")])
     assert r.returncode == 1 and "32x8" in r.stderr
     # matching header, truncated payload
-    hdr = struct.pack("<8siiqQq", b"RTMIACC1", 16, 8, 4, 2023, 0)
+    hdr = struct.pack("<8siiqQq", b"RTMIACC2", 16, 8, 4, 2023, 24)
     short = tmp_path / "short.bin"
     short.write_bytes(hdr + bytes(100))
     r = _run(["--rtiow", "-w", "16", "-h", "8", "-spp", "2", "--acc-in", str(short), "-o", str(tmp_path / "o.ppm")])
@@ -108,4 +117,4 @@ def test_cli_resumed_run_writes_the_same_ppm(tmp_path):
     assert one.read_bytes() == b.read_bytes()
     assert a.read_bytes() != b.read_bytes()
     hdr = struct.unpack("<8siiqQq", part.read_bytes()[:40])
-    assert hdr[:5] == (b"RTMIACC1", 80, 45, 12, 2023)
+    assert hdr == (b"RTMIACC2", 80, 45, 12, 2023, 24)

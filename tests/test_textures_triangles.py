@@ -350,3 +350,12 @@ def test_png_textures(rtmi, tmp_path):
     (tmp_path / "cut.png").write_bytes(good[: len(good) // 2])
     with pytest.raises(rtmi.RtmiError):
         sc.image_texture(str(tmp_path / "cut.png"))
+    # a deflate bomb: a header that says 4 x 4 in front of 8 MB of zeros (8 KB compressed): refused as soon as the stream
+    # outgrows the image it belongs to, not inflated first
+    import struct, zlib
+    chunk = lambda tag, data: struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    bomb = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(bytes(8 << 20), 9)) + chunk(b"IEND", b""))
+    (tmp_path / "bomb.png").write_bytes(bomb)
+    with pytest.raises(rtmi.RtmiError, match="expands beyond"):
+        sc.image_texture(str(tmp_path / "bomb.png"))
