@@ -446,6 +446,12 @@ def roofline_of(rtmi, scene, mine, args, chunk, world, k_ms, np):
             if key in tf:
                 roof["traffic"] = tf[key]["bytes_per_launch"]
                 roof["traffic_ratio_vs_survey_bytes"] = round(tf[key]["bytes_per_launch"] / roof["hbm_survey_bytes"], 2)
+                if tf[key].get("valu_insts") and roof.get("tests_per_sample"):
+                    # share of the issued vector lane slots that are SURVEY 8(d) sphere tests (12 instructions each): what the
+                    # 8(d) fraction hides -- tracked per round next to the lane utilisation
+                    tests = roof["tests_per_sample"]["sphere"] * roof["counts"]["samples"]
+                    roof["useful_valu_share"] = round(12.0 * tests / (64.0 * tf[key]["valu_insts"]), 4)
+                    roof["valu_lane_utilization"] = tf[key].get("valu_lane_utilization")
                 roof["traffic_source"] = {"kind": "static: PMC passes of this command, not re-collected in this run",
                                           "file": "profiles/hbm_traffic.json", "detail": tf[key].get("source"),
                                           "profiled_at_head": tf[key].get("head"), "this_head": _git_head()}

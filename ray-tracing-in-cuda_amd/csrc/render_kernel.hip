@@ -411,18 +411,24 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             };
             // the point where the ray meets a triangle's plane and its ray parameter (hittable.py:44-52, 61):
             // n = the unit normal turned towards the origin, theta = d.n / |d| < 0, r = o - d/|d| (oc.n) / theta
+            // (|d| and d / |d| belong to the ray, not to the triangle: one square root and three divisions per query instead of per
+            //  test -- a triangle test is about 190 instructions, 41 of them these)
+            float tq_a = 1.0f, tq_ux = 0.0f, tq_uy = 0.0f, tq_uz = 0.0f;
+            if (EXT && nt > 0 && active) {
+                tq_a = rt_sqrtf(ra);
+                tq_ux = dx / tq_a, tq_uy = dy / tq_a, tq_uz = dz / tq_a;
+            }
             auto tri_plane = [&](const float4 r0, const float4 r1, const float4 r2, float &rix, float &riy, float &riz,
                                  float &root) -> bool {
                 float tnx = r0.w, tny = r1.w, tnz = r2.w;
                 float ocn = dot3(ox - r0.x, oy - r0.y, oz - r0.z, tnx, tny, tnz);
                 if (ocn < 0.0f) tnx = -tnx, tny = -tny, tnz = -tnz, ocn = -ocn;
-                const float a = rt_sqrtf(ra);
-                const float theta = dot3(dx, dy, dz, tnx, tny, tnz) / a;
+                const float theta = dot3(dx, dy, dz, tnx, tny, tnz) / tq_a;
                 if (!(theta < 0.0f)) return false;
-                rix = ox - ((dx / a) * ocn) / theta;
-                riy = oy - ((dy / a) * ocn) / theta;
-                riz = oz - ((dz / a) * ocn) / theta;
-                root = ((-ocn) / theta) / a;
+                rix = ox - (tq_ux * ocn) / theta;
+                riy = oy - (tq_uy * ocn) / theta;
+                riz = oz - (tq_uz * ocn) / theta;
+                root = ((-ocn) / theta) / tq_a;
                 return true;
             };
 #define RT_SPHERE_TEST(S, IDX)                                                                 \

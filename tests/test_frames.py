@@ -94,7 +94,7 @@ def _png_rgb(path):
 
 
 @pytest.mark.gpu
-def test_rtmi_frames_driver(rtmi, golden_dir, tmp_path):
+def test_rtmi_frames_driver(rtmi, rtcheck, golden_dir, tmp_path):
     exe = os.path.join(os.path.dirname(rtmi.LIB_PATH), "rtmi-frames")
     tmpl = os.path.join(golden_dir, "scenes", "blue2.json")
     out = str(tmp_path / "f_%03d.png")
@@ -108,6 +108,9 @@ def test_rtmi_frames_driver(rtmi, golden_dir, tmp_path):
         sc.rotate_cylinders(2.0 * (k + 1))  # blue2.py bumps the angle before writing frame k
         want = rtmi.quantize_rgb8(sc.render(rtmi.Opts(seed=9)), 4, gamma=False)
         np.testing.assert_array_equal(_png_rgb(out % k), want)
+        if k == 1:  # ... and one frame against the CPU checker's pixels (not only the library against itself)
+            ref, _ = rtcheck.oracle_render(sc, seed=9)
+            np.testing.assert_array_equal(_png_rgb(out % k), rtmi.quantize_rgb8(ref, 4, gamma=False))
         dumped = rtmi.Scene.load(str(tmp_path / ("s_%03d.json" % k)))
         assert dumped.prims().tobytes() == sc.prims().tobytes() and dumped.output_file == out % k
     # the DNA animation, two frames
@@ -117,4 +120,6 @@ def test_rtmi_frames_driver(rtmi, golden_dir, tmp_path):
     sc = rtmi.Scene.dna(6)
     sc.override(width=48, height=27, spp=2)
     np.testing.assert_array_equal(_png_rgb(str(tmp_path / "d_006.png")), rtmi.quantize_rgb8(sc.render(), 2, gamma=False))
+    ref, _ = rtcheck.oracle_render(sc, seed=rtmi.Opts().seed)
+    np.testing.assert_array_equal(_png_rgb(str(tmp_path / "d_006.png")), rtmi.quantize_rgb8(ref, 2, gamma=False))
     assert "total time" in r.stderr

@@ -528,6 +528,31 @@ def test_clumps_keep_their_grid(rtmi, rtcheck):
     assert np.array_equal(img, big.render(rtmi.Opts(seed=SEED, variant=16)))
 
 
+def test_headline_kernel_is_counted_by_the_3d_walk_over_the_same_cells(rtmi, rtcheck):
+    """bench.py's roofline counts come from the counting build of the 3-D grid walk (variant 6), while the headline frame
+    is rendered by the x-z walk (variant 2) that variant 0 picks for RTIOW's one-cell-high grid.  Same scene as the bench
+    (rt_scene_rtiow(7)), smaller frame: the two kernels' images are equal, the counting launch reports which kernel ran, its
+    event counts equal the CPU checker's, and asking it for variant 0, 2 or 6 gives the same counters."""
+    sc = rtmi.Scene.rtiow(7, 192, 108, 8, 50)
+    st = rtmi.Stats()
+    sheet = sc.render(rtmi.Opts(seed=SEED), st)
+    assert st.kernel_variant == 2
+    walk3d = sc.render(rtmi.Opts(seed=SEED, variant=6))
+    assert np.array_equal(sheet, walk3d)
+    counts = {}
+    for asked in (0, 2, 6):
+        c, img = sc.count(rtmi.Opts(seed=SEED, variant=asked), want_image=True)
+        assert c.kernel_variant == 6 and c.cull_mode == 5 and c.grid_sheet == 1
+        assert np.array_equal(img, sheet)
+        d = c.as_dict()
+        counts[asked] = {k: d[k] for k in ("samples", "queries", "hits", "misses", "scatter", "rng_draws", "lane_clusters",
+                                           "lane_groups", "lane_cands", "cand_lanes")}
+    assert counts[0] == counts[2] == counts[6]
+    _, want = rtcheck.oracle_render(sc, seed=SEED, want_counts=True)
+    for k, v in want.items():
+        assert c.as_dict()[k] == v, k
+
+
 def test_sheet_walk_equals_the_3d_walk_and_the_flat_scan(rtmi, rtcheck):
     """A grid that is one cell high (RTIOW's spheres on the ground) is walked along x and z only (variant 2, what
     variant 0 picks by itself there).  Same cells, same tests, same bytes as the 3-D walk (variant 6) and as the

@@ -12,7 +12,8 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         out["kernel_stats"].append({k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
-        if "render_kernel<false, true, true, false, 5," in r["Kernel_Name"] or "render_kernel<false, true, true, false, 6," in r["Kernel_Name"]:  # the default kernel (6: its x-z walk for sheets)
+        # the headline kernel: render_kernel<COUNT = false, POOL, SCALAR = false, CULL = 6 (x-z walk) or 5, EXT = false, SPH = true>
+        if "render_kernel<false, true, false, 6, false, true>" in r["Kernel_Name"] or "render_kernel<false, true, false, 5, false, true>" in r["Kernel_Name"]:
             out["render_dispatch"] = {k: r[k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")}
             break
 agg = collections.defaultdict(float); launches = collections.defaultdict(int)
@@ -38,6 +39,18 @@ if "SQ_LDS_BANK_CONFLICT" in p and "SQ_LDS_IDX_ACTIVE" in p:
 if "SQ_WAVE_CYCLES" in p:
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in p: d[k.lower() + "_frac_of_wave_cycles"] = p[k] / p["SQ_WAVE_CYCLES"]
+# useful VALU share: the 17-flop sphere tests of SURVEY 8(d), 12 vector instructions per lane each, over
+# every lane slot the kernel issued (64 x SQ_INSTS_VALU) -- the tests per launch come from the bench line of the trace pass
+try:
+    line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith('{"metric"')][-1]
+    roof = json.loads(line)["roofline"]
+    tests = roof["tests_per_sample"]["sphere"] * roof["counts"]["samples"]
+    if "SQ_INSTS_VALU" in p:
+        d["sphere_tests_per_launch"] = tests
+        d["useful_valu_share"] = 12.0 * tests / (64.0 * p["SQ_INSTS_VALU"])
+        d["valu_insts_per_launch"] = p["SQ_INSTS_VALU"]
+except Exception as e:
+    d["useful_valu_share_error"] = repr(e)
 if "FETCH_SIZE" in p: d["hbm_read_bytes_per_launch"] = p["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE reads 1/2 (MI355X_MICROARCH.md HBM)
 if "WRITE_SIZE" in p: d["hbm_write_bytes_per_launch"] = p["WRITE_SIZE"] * 1024
 out["derived"] = d
@@ -47,6 +60,8 @@ if "hbm_read_bytes_per_launch" in d and "hbm_write_bytes_per_launch" in d:
     tf = {"1920x1080x1024": {"bytes_per_launch": int(d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]),
                              "read_bytes": int(d["hbm_read_bytes_per_launch"]), "write_bytes": int(d["hbm_write_bytes_per_launch"]),
                              "head": head,
+                             "valu_insts": d.get("valu_insts_per_launch"), "valu_lane_utilization": d.get("valu_lane_utilization"),
+                             "useful_valu_share": d.get("useful_valu_share"),
                              "source": f"profiles/{tag}_rocprof_summary.json: rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and WRITE_SIZE, separate passes, render_kernel only"}}
     json.dump(tf, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out["derived"], indent=1)); print(out.get("render_dispatch")); 
