@@ -157,10 +157,11 @@ def main():
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        with stdout_to_stderr():  # (RCCL's version banner)
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     scene = rtmi.Scene.rtiow(7, args.width, args.height, args.spp, args.depth)
     chunk = args.chunk if args.chunk >= 0 else 0  # 0 = the library's default work-item size
@@ -190,7 +191,10 @@ def main():
     # one-time set-up outside any timed or warm-up step: scene image upload, accumulator allocation and
     # occupancy query, and the communicator's first collective.  It is the same launch as a step, so that
     # every render_kernel row of a `rocprofv3 --stats` summary of this command is one step's launch.
-    step()
+    with stdout_to_stderr():
+        step()
+        if world > 1:
+            dist.barrier()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -268,6 +272,20 @@ def main():
         dist.destroy_process_group()
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on the process's stdout at the first communicator: keep stdout to the ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def tiles_abi_frames(rtmi, scene, base, devices, steps, np, reference=None):
     """rt_render_hip_tiles (include/rtmi.h; csrc/tiles.hip) on `devices`: the first call (streams, buffers, ncclCommInitAll)
     apart, then `steps` frames.  Wall time per frame from call to return = render + gather + row placement + copy of the
@@ -275,7 +293,8 @@ def tiles_abi_frames(rtmi, scene, base, devices, steps, np, reference=None):
     o = rtmi.Opts(seed=base.seed, tile_rows=base.tile_rows, spp_chunk=base.spp_chunk, variant=base.variant)
     st = rtmi.Stats()
     t0 = time.perf_counter()
-    img = scene.render_tiles(devices=devices, opts=o, stats=st)
+    with stdout_to_stderr():
+        img = scene.render_tiles(devices=devices, opts=o, stats=st)
     first = time.perf_counter() - t0
     wall, kern, gath = [], [], []
     for _ in range(steps):
@@ -315,7 +334,8 @@ def tiles_abi_main(args) -> int:
     base = rtmi.Opts(seed=args.seed, tile_rows=args.tile_rows, spp_chunk=chunk, variant=args.variant)
     devices = list(range(args.gpus))
     st = rtmi.Stats()
-    img = scene.render_tiles(devices=devices, opts=base, stats=st)  # set-up: scene upload, streams, RCCL communicators
+    with stdout_to_stderr():
+        img = scene.render_tiles(devices=devices, opts=base, stats=st)  # set-up: scene upload, streams, RCCL communicators
     for _ in range(args.warmup):
         img = scene.render_tiles(devices=devices, opts=base, stats=st)
     kern, gath = [], []
