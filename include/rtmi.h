@@ -244,6 +244,12 @@ typedef struct rt_opts {
     int32_t tile_rows;   /* 0 -> 8                                             */
     int32_t tile_first;
     int32_t tile_stride;
+    /* 1: ROTATED interleave -- of every group of tile_stride consecutive tiles the shard tile_first owns one, and which one
+     * rotates from group to group: its k-th tile is k * tile_stride + ((tile_first - k) mod tile_stride), i.e. tile t
+     * belongs to shard (t + t / tile_stride) mod tile_stride.  Same number of tiles per shard as the plain interleave,
+     * but no shard keeps one row phase of the image for itself (RTIOW 1080p over 8 shards: the shards' work differs by
+     * +-0.4 % instead of +-1.8 %).  rt_render_hip_tiles and bench.py split frames this way.  0: the plain interleave above. */
+    int32_t tile_rotate;
     /* samples per work item (one wave renders an 8x8 tile x spp_chunk samples at a time).
      * Scheduling only: the per-pixel sum is exact (64-bit fixed point, 2^-24), so the
      * framebuffer does not depend on it.  0 -> 128 (less for small frames).          */
@@ -370,7 +376,8 @@ int rt_shard_scatter_rows(const rt_scene *s, const rt_opts *o, const float *loca
                           float *full_rgb);
 
 /* the same on the device, for a GATHERED buffer: d_gathered[n_ranks][pad_rows][W][3] holds rank r's dense local
- * rows (tile t of the frame = local tile t / n_ranks of rank t mod n_ranks; pad_rows >= the largest shard), as
+ * rows (tile t of the frame = local tile t / n_ranks of rank t mod n_ranks, or of rank (t + t / n_ranks) mod n_ranks
+ * when o->tile_rotate is set: how the shards were cut; pad_rows >= the largest shard), as
  * ncclGather delivers them; one kernel on `stream` (hipStream_t as void*) writes d_full[H][W][3].
  * rt_render_hip_tiles uses it on its root device. */
 int rt_shard_place_rows_device(const rt_scene *s, const rt_opts *o, int n_ranks, int pad_rows,

@@ -82,7 +82,7 @@ class Opts(C.Structure):
     """rt_opts (include/rtmi.h)."""
     _fields_ = [
         ("seed", C.c_uint64), ("device", C.c_int32), ("tile_rows", C.c_int32), ("tile_first", C.c_int32),
-        ("tile_stride", C.c_int32), ("spp_chunk", C.c_int32), ("sample_first", C.c_int32),
+        ("tile_stride", C.c_int32), ("tile_rotate", C.c_int32), ("spp_chunk", C.c_int32), ("sample_first", C.c_int32),
         ("sample_count", C.c_int32), ("variant", C.c_uint32),
     ]
 

@@ -72,6 +72,7 @@ enum MatKind : int32_t {
 struct ItemParams {
     int32_t tiles_x, bands, num_items, sample_first, sample_count, spp_chunk, n_big, n_med, q_med, q_small;
     int32_t tile_rows, tile_first, tile_stride, local_rows;
+    int32_t tile_rotate;  // 1: the shard's k-th tile is k * tile_stride + ((tile_first - k) mod tile_stride) (include/rtmi.h)
 };
 
 // kernel parameter block (passed by value: lands in SGPRs / the kernarg segment)

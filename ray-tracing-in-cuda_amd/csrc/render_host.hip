@@ -830,13 +830,22 @@ static void pack_scene(const Scene &s, DeviceSceneCache &c) {
 
 // ---- shard geometry ----------------------------------------------------------------
 struct Shard {
-    int tile_rows, tile_first, tile_stride, num_tiles, local_tiles, local_rows;
+    int tile_rows, tile_first, tile_stride, tile_rotate, num_tiles, local_tiles, local_rows;
 };
+
+// the k-th row tile of a shard (rt_opts: plain or rotated interleave)
+static inline int shard_tile(const Shard &sh, int k) {
+    if (!sh.tile_rotate) return sh.tile_first + k * sh.tile_stride;
+    int j = (sh.tile_first - k) % sh.tile_stride;
+    if (j < 0) j += sh.tile_stride;
+    return k * sh.tile_stride + j;
+}
 
 static int shard_of(const Scene &s, const rt_opts *o, Shard &sh) {
     sh.tile_rows = (o && o->tile_rows > 0) ? o->tile_rows : 8;
     sh.tile_first = o ? o->tile_first : 0;
     sh.tile_stride = (o && o->tile_stride > 1) ? o->tile_stride : 1;
+    sh.tile_rotate = (o && o->tile_rotate && sh.tile_stride > 1) ? 1 : 0;
     sh.num_tiles = (s.height + sh.tile_rows - 1) / sh.tile_rows;
     if (sh.tile_first < 0 || (sh.tile_stride > 1 && sh.tile_first >= sh.tile_stride)) {
         set_error("tile_first %d out of range for tile_stride %d", sh.tile_first, sh.tile_stride);
@@ -844,7 +853,12 @@ static int shard_of(const Scene &s, const rt_opts *o, Shard &sh) {
     }
     sh.local_tiles = 0;
     sh.local_rows = 0;
-    for (int t = sh.tile_first; t < sh.num_tiles; t += sh.tile_stride) {
+    // (only the last group of tile_stride tiles can be incomplete, so a shard's tiles are its local tiles 0 .. local_tiles - 1)
+    for (int k = 0;; ++k) {
+        const long long t64 = sh.tile_rotate ? (long long)k * sh.tile_stride : (long long)sh.tile_first + (long long)k * sh.tile_stride;
+        if (t64 >= sh.num_tiles) break;
+        const int t = shard_tile(sh, k);
+        if (t >= sh.num_tiles) break;
         int rows = s.height - t * sh.tile_rows;
         if (rows > sh.tile_rows) rows = sh.tile_rows;
         sh.local_rows += rows;
@@ -855,7 +869,7 @@ static int shard_of(const Scene &s, const rt_opts *o, Shard &sh) {
 
 static int shard_global_row(const Shard &sh, int local_row) {
     int tl = local_row / sh.tile_rows;
-    return (sh.tile_first + tl * sh.tile_stride) * sh.tile_rows + (local_row - tl * sh.tile_rows);
+    return shard_tile(sh, tl) * sh.tile_rows + (local_row - tl * sh.tile_rows);
 }
 
 }  // namespace rtmi
@@ -1232,6 +1246,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             ip.sample_first = P.sample_first, ip.sample_count = P.sample_count, ip.spp_chunk = P.spp_chunk;
             ip.n_big = P.n_big, ip.n_med = P.n_med, ip.q_med = P.q_med, ip.q_small = P.q_small;
             ip.tile_rows = P.tile_rows, ip.tile_first = P.tile_first, ip.tile_stride = P.tile_stride;
+            ip.tile_rotate = sh.tile_rotate;
             ip.local_rows = P.local_rows;
             launch_item_params(d_queue, ip, stream);
         }

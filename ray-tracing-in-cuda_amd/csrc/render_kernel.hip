@@ -306,12 +306,19 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         return reinterpret_cast<const int4 *>(queue + RT_ITEM_PARAMS_AT)[quad];
     };
     auto home_pixel = [&](int x0, int band, int &hx, int &hlr, int &hy, int &hvalid) {
-        const int4 g = ipar4(3);  // q_small (unused here) is not in this quad: {tile_rows, tile_first, tile_stride, local_rows}
+        const int4 g = ipar4(3);  // {tile_rows, tile_first, tile_stride, local_rows}
         const int tile_rows = g.x, tile_first = g.y, tile_stride = g.z, local_rows = g.w;
+        const int tile_rotate = ipar4(2).z;
         hx = x0 + (lane & 7);
         hlr = band * 8 + (lane >> 3);
         const int htl = hlr / tile_rows;
-        hy = (tile_first + htl * tile_stride) * tile_rows + (hlr - htl * tile_rows);
+        int tile = tile_first + htl * tile_stride;
+        if (tile_rotate) {  // rotated interleave (include/rtmi.h, rt_opts.tile_rotate)
+            int j = (tile_first - htl) % tile_stride;
+            if (j < 0) j += tile_stride;
+            tile = htl * tile_stride + j;
+        }
+        hy = tile * tile_rows + (hlr - htl * tile_rows);
         hvalid = (hx < P.width && hlr < local_rows && hy < P.height) ? 1 : 0;
     };
     // tile accumulator -> global accumulators (image[y*W + x] += res, main.cu:104; other sample chunks of the same
@@ -1707,9 +1714,9 @@ bool variant_exists(unsigned variant) { return variant == 0 || variant_cull_mode
 __global__ void item_params_kernel(unsigned int *queue, ItemParams ip) {
     int *dst = reinterpret_cast<int *>(queue) + RT_ITEM_PARAMS_AT;
     // quad 0: tiles_x, bands, num_items, sample_first; quad 1: sample_count, spp_chunk, n_big, n_med;
-    // quad 2: q_med, q_small, -, -; quad 3: tile_rows, tile_first, tile_stride, local_rows
+    // quad 2: q_med, q_small, tile_rotate, -; quad 3: tile_rows, tile_first, tile_stride, local_rows
     const int v[16] = {ip.tiles_x, ip.bands, ip.num_items, ip.sample_first, ip.sample_count, ip.spp_chunk, ip.n_big,
-                       ip.n_med, ip.q_med, ip.q_small, 0, 0, ip.tile_rows, ip.tile_first, ip.tile_stride, ip.local_rows};
+                       ip.n_med, ip.q_med, ip.q_small, ip.tile_rotate, 0, ip.tile_rows, ip.tile_first, ip.tile_stride, ip.local_rows};
     for (int k = 0; k < 16; ++k) dst[k] = v[k];
 }
 

@@ -80,17 +80,18 @@ static RcclApi *rccl_api() {
     } while (0)
 
 // gathered[rank][pad_rows][W][3] (each rank's local rows dense, tile t of the frame = local tile t / N of rank
-// t mod N)  ->  full[H][W][3].  One thread per float; consecutive threads read and write consecutive floats.
+// (t + t / N) mod N: the rotated interleave of rt_opts.tile_rotate)  ->  full[H][W][3].  One thread per float;
+// consecutive threads read and write consecutive floats.
 __global__ __launch_bounds__(256) void place_rows_kernel(const float *__restrict__ gathered, float *__restrict__ full,
                                                          int height, int row_floats, int tile_rows, int n_ranks,
-                                                         int pad_rows) {
+                                                         int pad_rows, int rotate) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)height * row_floats;
     if (i >= total) return;
     const int y = (int)(i / row_floats);
     const int c = (int)(i - (size_t)y * row_floats);
     const int t = y / tile_rows;
-    const int rank = t % n_ranks;
+    const int rank = rotate ? (t % n_ranks + t / n_ranks) % n_ranks : t % n_ranks;
     const int local_row = (t / n_ranks) * tile_rows + (y - t * tile_rows);
     full[i] = gathered[((size_t)rank * pad_rows + local_row) * row_floats + c];
 }
@@ -225,6 +226,7 @@ extern "C" int rt_render_hip_tiles(const rt_scene *sc, const rt_opts *o, const i
         shard[r].device = devs[r];
         shard[r].tile_first = r;
         shard[r].tile_stride = N;
+        shard[r].tile_rotate = N > 1 ? 1 : 0;
         const int rows = rt_shard_rows(sc, &shard[r]);
         if (rows < 0) return -rows;
         pad_rows = std::max(pad_rows, rows);
@@ -308,7 +310,7 @@ extern "C" int rt_render_hip_tiles(const rt_scene *sc, const rt_opts *o, const i
     const size_t total = (size_t)H * row_floats;
     if (total) {
         hipLaunchKernelGGL(place_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g->streams[0], g->gathered,
-                           g->full, H, (int)row_floats, base.tile_rows, N, pad_rows);
+                           g->full, H, (int)row_floats, base.tile_rows, N, pad_rows, N > 1 ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(g->ev_done, g->streams[0]));
@@ -353,6 +355,7 @@ extern "C" int rt_shard_place_rows_device(const rt_scene *sc, const rt_opts *o, 
         return RT_ERR_ARG;
     }
     const int tile_rows = (o && o->tile_rows > 0) ? o->tile_rows : 8;
+    const int rotate = (o && o->tile_rotate && n_ranks > 1) ? 1 : 0;  // how the ranks' shards were cut (rt_opts.tile_rotate)
     const int W = sc->s.width, H = sc->s.height;
     const int tiles = (H + tile_rows - 1) / tile_rows;
     const int need = ((tiles + n_ranks - 1) / n_ranks) * tile_rows;  // rows of the largest shard, rounded up to whole tiles
@@ -360,7 +363,7 @@ extern "C" int rt_shard_place_rows_device(const rt_scene *sc, const rt_opts *o, 
         // the exact requirement is max over ranks of rt_shard_rows(); `need` over-estimates it by < tile_rows
         rt_opts probe;
         rt_opts_default(&probe);
-        probe.tile_rows = tile_rows, probe.tile_stride = n_ranks;
+        probe.tile_rows = tile_rows, probe.tile_stride = n_ranks, probe.tile_rotate = rotate;
         int worst = 0;
         for (int r = 0; r < n_ranks; ++r) {
             probe.tile_first = r;
@@ -374,7 +377,7 @@ extern "C" int rt_shard_place_rows_device(const rt_scene *sc, const rt_opts *o, 
     const size_t total = (size_t)H * W * 3;
     if (!total) return RT_OK;
     hipLaunchKernelGGL(place_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)d_gathered, (float *)d_full, H, W * 3, tile_rows, n_ranks, pad_rows);
+                       (const float *)d_gathered, (float *)d_full, H, W * 3, tile_rows, n_ranks, pad_rows, rotate);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }

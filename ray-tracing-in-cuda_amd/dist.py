@@ -2,8 +2,9 @@
 
 The reference's only multi-GPU mechanism is one renderer PROCESS per GPU per animation
 frame (gpu-version/blue.py:23-32, CUDA_VISIBLE_DEVICES=k); nothing is exchanged.  Here one
-frame is split: row tile t (tile_rows full-width rows) belongs to rank t mod world, so
-sky rows and ground rows are spread evenly; pixels are independent and the RNG is keyed
+frame is split: row tile t (tile_rows full-width rows) belongs to rank (t + t // world) mod world
+(an interleave whose phase rotates from one group of `world` tiles to the next), so sky rows and
+ground rows are spread evenly and no rank keeps one row phase of the image; pixels are independent and the RNG is keyed
 by the GLOBAL pixel id, so the assembled image is bit-identical for every world size.
 The only communication is ONE gather of the rank-local row buffers to the root
 (torch.distributed.gather -> ncclGather over xGMI with the nccl (= RCCL) backend, gloo in
@@ -25,6 +26,7 @@ def shard_opts(base: Opts, rank: int, world: int) -> Opts:
         setattr(o, name, getattr(base, name))
     o.tile_first = rank
     o.tile_stride = world
+    o.tile_rotate = 1 if world > 1 else 0  # rotated interleave: no rank keeps one row phase of the image (include/rtmi.h)
     return o
 
 

@@ -34,7 +34,7 @@ def test_struct_layouts_match_checker(rtmi):
     assert rtmi.PRIM_DTYPE.itemsize == 128
     assert rtmi.MATERIAL_DTYPE.itemsize == 28
     assert rtmi.TEXTURE_DTYPE.itemsize == 28
-    assert ctypes.sizeof(rtmi.Opts) == 40
+    assert ctypes.sizeof(rtmi.Opts) == 48
     # the ctypes mirrors against the structs the library was compiled with
     assert ctypes.sizeof(rtmi.Opts) == rtmi.struct_size(0)
     assert ctypes.sizeof(rtmi.Stats) == rtmi.struct_size(1)

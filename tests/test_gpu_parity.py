@@ -103,12 +103,14 @@ def test_partition_invariance(rtmi, scenes_dir, golden_dir, world, tile_rows):
     sc.override(width=72, height=45, spp=4)
     full = sc.render(rtmi.Opts(seed=SEED))
     out = np.zeros_like(full)
-    for r in range(world):
-        o = rtmi.Opts(seed=SEED, tile_rows=tile_rows, tile_first=r, tile_stride=world)
-        local = sc.render(o)
-        assert local.shape[0] == sc.shard_rows(o)
-        sc.scatter_rows(o, local, out)
-    assert np.array_equal(out, full)
+    for rotate in (0, 1):  # the plain and the rotated interleave (rt_opts.tile_rotate)
+        out[:] = 0
+        for r in range(world):
+            o = rtmi.Opts(seed=SEED, tile_rows=tile_rows, tile_first=r, tile_stride=world, tile_rotate=rotate)
+            local = sc.render(o)
+            assert local.shape[0] == sc.shard_rows(o)
+            sc.scatter_rows(o, local, out)
+        assert np.array_equal(out, full)
 
 
 def test_sample_chunks_and_ranges(rtmi, rtcheck, scenes_dir, golden_dir):
@@ -301,7 +303,7 @@ def test_full_frame_properties(rtmi, rtcheck):
     assert np.array_equal(full, sc.render(rtmi.Opts(seed=SEED)))
     out = np.zeros_like(full)
     for r in range(8):
-        o = rtmi.Opts(seed=SEED, tile_first=r, tile_stride=8)
+        o = rtmi.Opts(seed=SEED, tile_first=r, tile_stride=8, tile_rotate=1)
         sc.scatter_rows(o, sc.render(o), out)
     assert np.array_equal(out, full)
     osc = rtcheck.OracleScene(sc)

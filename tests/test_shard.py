@@ -24,6 +24,21 @@ def test_shard_geometry(rtmi, scenes_dir):
             allrows += list(rows)
         assert sorted(allrows) == list(range(45))
         seen.append(world)
+    # the rotated interleave (rt_opts.tile_rotate: what rt_render_hip_tiles and bench.py use): tile t -> rank (t + t // world)
+    # mod world -- one tile of every group of `world` tiles per rank, a different one from group to group
+    for world in (2, 3, 4, 8):
+        allrows, counts = [], []
+        for r in range(world):
+            o = rtmi.Opts(tile_first=r, tile_stride=world, tile_rotate=1)
+            rows = sc.shard_global_rows(o)
+            t = np.asarray(rows) // 8
+            assert np.array_equal((t + t // world) % world, np.full(len(rows), r))
+            assert list(rows) == sorted(rows) and sc.shard_rows(o) == len(rows)
+            if len(set(t)) > 1:
+                assert len(set(t % world)) > 1                      # not one row phase for itself
+            allrows += list(rows)
+            counts.append(len(set(t)))
+        assert sorted(allrows) == list(range(45)) and max(counts) - min(counts) <= 1
     # tile_rows other than 8, partial last tile
     rows = sc.shard_global_rows(rtmi.Opts(tile_rows=16, tile_first=1, tile_stride=2))
     assert list(rows) == list(range(16, 32))

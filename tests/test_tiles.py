@@ -47,13 +47,23 @@ def test_tiles_argument_errors(rtmi):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rotate", [1, 0])
 @pytest.mark.parametrize("world,tile_rows,h", [(2, 8, 54), (3, 8, 45), (8, 8, 1080 // 4), (5, 16, 77), (8, 4, 30)])
-def test_gathered_layout_placement_kernel(rtmi, world, tile_rows, h):
-    """What the root does after the gather, for N > 1: shards laid out [rank][pad_rows][W][3] -> the frame."""
+def test_gathered_layout_placement_kernel(rtmi, world, tile_rows, h, rotate):
+    """What the root does after the gather, for N > 1: shards laid out [rank][pad_rows][W][3] -> the frame.  rotate = 1 is
+    the split rt_render_hip_tiles and bench.py use (rt_opts.tile_rotate: tile t belongs to shard (t + t // N) mod N)."""
     import torch
     sc = rtmi.Scene.rtiow(7, 120, h, 2, 50)
     want = sc.render(rtmi.Opts(seed=SEED))
-    shards = [rtmi.Opts(seed=SEED, tile_rows=tile_rows, tile_first=r, tile_stride=world) for r in range(world)]
+    shards = [rtmi.Opts(seed=SEED, tile_rows=tile_rows, tile_first=r, tile_stride=world, tile_rotate=rotate) for r in range(world)]
+    owners = np.full(h, -1)
+    for r, o in enumerate(shards):  # every row belongs to exactly one shard; tile t to shard (t + t // N) % N or t % N
+        rows = sc.shard_global_rows(o)
+        assert (owners[rows] == -1).all()
+        owners[rows] = r
+        t = np.asarray(rows) // tile_rows
+        assert np.array_equal((t + t // world) % world if rotate else t % world, np.full(len(rows), r))
+    assert (owners >= 0).all()
     pad = max(sc.shard_rows(o) for o in shards)
     gathered = torch.full((world, pad, 120, 3), float("nan"), dtype=torch.float32, device="cuda:0")
     for r, o in enumerate(shards):
@@ -61,12 +71,12 @@ def test_gathered_layout_placement_kernel(rtmi, world, tile_rows, h):
         if rows:
             sc.render_device(o, gathered[r].data_ptr(), torch.cuda.current_stream().cuda_stream)
     full = torch.empty((h, 120, 3), dtype=torch.float32, device="cuda:0")
-    sc.place_rows_device(rtmi.Opts(tile_rows=tile_rows), world, pad, gathered.data_ptr(), full.data_ptr(),
+    sc.place_rows_device(rtmi.Opts(tile_rows=tile_rows, tile_rotate=rotate), world, pad, gathered.data_ptr(), full.data_ptr(),
                          torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(full.cpu().numpy(), want)
     with pytest.raises(rtmi.RtmiError, match="pad_rows"):
-        sc.place_rows_device(rtmi.Opts(tile_rows=tile_rows), world, pad - 1, gathered.data_ptr(), full.data_ptr(), 0)
+        sc.place_rows_device(rtmi.Opts(tile_rows=tile_rows, tile_rotate=rotate), world, pad - 1, gathered.data_ptr(), full.data_ptr(), 0)
 
 
 @pytest.mark.gpu
