@@ -330,7 +330,7 @@ static bool pack_scene_once(const Scene &s, DeviceSceneCache &c, std::vector<cha
     // sphere entries per tier and <= 4095 other entries per cell).
     std::vector<uint32_t> grid_cells;   // compact: (first item << 12) | (n_near << 6) | n_all;  wide: {first item, n_near | n_all << 10 | n_other << 20}
     std::vector<uint32_t> grid_items;   // sphere slots (a cell's near-tier entries first), then grouped ids of the other primitives
-    bool grid_wide = !sphere_only || ns_slots >= 65536;
+    bool grid_wide = !sphere_only || ns_slots >= 65536 || knob_set("RTMI_FORCE_WIDE");  // (the knob: measurement)
     float grid_min[3] = {0, 0, 0}, grid_size[3] = {1, 1, 1};
     int grid_n[3] = {0, 0, 0};
     float grid_ob2[2] = {0.0f, 0.0f}, grid_shrink = 0.0f;
