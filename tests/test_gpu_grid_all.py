@@ -166,3 +166,46 @@ def test_counting_kernel_reports_the_kernel_that_ran(rtmi, rtcheck):
         st, cimg = mixed.count(rtmi.Opts(seed=SEED, variant=asked), want_image=True)
         assert st.kernel_variant == (44 if asked == 44 else 36) and st.cull_mode == 7, asked
         assert np.array_equal(cimg, ref), asked
+
+
+def test_grid_of_other_primitives_only_and_rays_along_its_planes(rtmi, rtcheck):
+    """No sphere at all: the grid is built over rectangles, triangles and cylinders alone.  The primitives sit ON the lattice
+    planes of a regular arrangement (so their boxes end exactly on cell boundaries), the camera's rays have direction
+    components of exactly 0 (they never leave their cell column), a long thin cylinder crosses the whole grid and a
+    triangle far larger than the rest is tested per query."""
+    sc = rtmi.Scene.new(9, 9, 4, 6)
+    sc.set_background((0.25, 0.5, 0.75), sky_gradient=False, defocus_blur=False)
+    sc.camera((1.0, 1.0, 30.0), (1.0, 1.0, 0.0), (0, 1, 0), 1e-6, 1.0, 0.0, 30.0)  # every ray: d = (0, 0, -1) exactly
+    lights = [sc.diffuse_light((1.0 + k, 2.0, 3.0)) for k in range(3)]
+    mirror = sc.metal((1, 1, 1), 0.0)
+    k = 0
+    for ix in range(-3, 5):
+        for iy in range(-3, 5):
+            for iz in range(3):
+                x, y, z = float(ix), float(iy), float(-2 * iz)
+                m = lights[k % 3] if (ix, iy) != (1, 1) or iz else mirror  # the camera's column: a mirror first
+                if k % 3 == 0:
+                    sc.xy_rect(x - 0.5, x + 0.5, y - 0.5, y + 0.5, z, m)
+                elif k % 3 == 1:
+                    sc.triangle((x - 0.5, y - 0.5, z), (x + 0.5, y - 0.5, z), (x, y + 0.5, z), m)
+                else:
+                    sc.cylinder(0.4, -0.5, 0.5, m, rotate=((1.0, 0.0, 0.0), 90.0), translate=(x, y, z))
+                k += 1
+    sc.cylinder(0.05, -40.0, 40.0, lights[0], rotate=((0.0, 1.0, 0.0), 90.0), translate=(0.0, 2.5, -1.0))  # through every column
+    sc.triangle((-60.0, -60.0, -9.0), (60.0, -60.0, -9.0), (0.0, 80.0, -9.0), lights[2])                   # a backdrop: oversized
+    assert all(int(t) != 0 for t in sc.prims()["type"])
+    st = rtmi.Stats()
+    img = sc.render(rtmi.Opts(seed=SEED), st)
+    assert st.kernel_variant == 44                      # (192 primitives of 5 - 6 records each: beyond the LDS budget)
+    ref, _ = rtcheck.oracle_render(sc, seed=SEED)
+    assert np.array_equal(img, ref)
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=16)))
+    assert np.array_equal(img, sc.render(rtmi.Opts(seed=SEED, variant=36)))  # the same tables from LDS
+    c = sc.count(rtmi.Opts(seed=SEED))
+    assert c.cull_mode == 7 and c.lane_groups > 0 and c.lane_clusters > 0   # lanes entered the grid and tested its entries
+    # a wider view of the same arrangement, from inside it
+    sc.camera((0.3, 0.2, -1.0), (3.0, 2.0, -3.0), (0, 1, 0), 80.0)
+    sc.override(width=64, height=48, spp=3)
+    img = sc.render(rtmi.Opts(seed=SEED))
+    ref, _ = rtcheck.oracle_render(sc, seed=SEED)
+    assert np.array_equal(img, ref)
