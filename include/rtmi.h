@@ -231,6 +231,31 @@ int rt_scene_get_prims(const rt_scene *s, rt_prim *out, int cap);         /* -> 
 int rt_scene_get_materials(const rt_scene *s, rt_material *out, int cap); /* -> count */
 int rt_scene_get_textures(const rt_scene *s, rt_texture *out, int cap);   /* -> count */
 
+/* The device tables the host builds for a scene (no GPU needed: host logic tests, tools).  The reference rebuilds its object
+ * graph on the device (move_to_device<<<1,1>>>, main.cu:374-446); here the host flattens the scene into ONE image of 16-byte
+ * records -- sphere slots, the other primitives' records and boxes, the uniform grid over every primitive type (cells + lists),
+ * cold records, materials -- which one memcpy uploads (csrc/device_scene.h, csrc/render_host.hip pack_scene). */
+typedef struct rt_table_info {
+    int32_t image_floats;      /* size of the image (rt_scene_table_image) */
+    int32_t grid_wide;         /* 1: wide tables (32-bit entries, two words per cell: every primitive type listed); 0: compact
+                                  (sphere-only scenes whose tables fit LDS: 16-bit entries, one word per cell) */
+    int32_t grid_sheet;        /* compact tables, grid one cell high */
+    int32_t grid_cells, grid_n[3];
+    float grid_min[3], grid_size[3];
+    float ob_near2, ob_far2;   /* squared reach of the lists' near / far tier (|ray origin|^2) */
+    int32_t ns, np, ncl;       /* sphere slots, leading always-tested slots, clusters of 8 (+ 1 never-hit slot each) behind them */
+    int32_t nr, nc, nt;        /* rectangles, cylinders, triangles ... */
+    int32_t nr_a, nc_a, nt_a;  /* ... of which the leading ones are tested for every query instead of being listed */
+    int32_t off_grid_cells, off_grid_items;                         /* record (float4) offsets into the image */
+    int32_t off_sph_cold, off_rect_cold, off_cyl_cold, off_tri_cold; /* cold records: {.., material, list index, kind} */
+    int32_t off_rect_hot, off_cyl_hot, off_tri_hot;
+    int32_t hot_bytes_grid;    /* what a grid-walk kernel stages into LDS */
+    int32_t kernel_variant;    /* what rt_opts.variant = 0 renders this scene with (2, 6, 16, 36 or 44) */
+} rt_table_info;
+int rt_scene_table_info(const rt_scene *s, rt_table_info *out);
+/* copies min(cap_floats, image_floats) floats of the image; returns image_floats, or -rt_status */
+int rt_scene_table_image(const rt_scene *s, float *out, int cap_floats);
+
 /* ---- render ------------------------------------------------------------ */
 
 typedef struct rt_opts {
@@ -405,7 +430,7 @@ const char *rt_last_error(void);
 const char *rt_status_string(int status);
 int rt_abi_version(void);
 /* sizeof of the ABI structs as this library was compiled (binding self-checks):
- * 0 rt_opts, 1 rt_stats, 2 rt_prim, 3 rt_material, 4 rt_texture, 5 rt_camera, 6 rt_scene_info; else 0 */
+ * 0 rt_opts, 1 rt_stats, 2 rt_prim, 3 rt_material, 4 rt_texture, 5 rt_camera, 6 rt_scene_info, 7 rt_table_info; else 0 */
 size_t rt_struct_size(int which);
 /* number of usable gfx950 devices, or -rt_status */
 int rt_device_count(void);

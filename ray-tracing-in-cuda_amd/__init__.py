@@ -118,6 +118,21 @@ class Stats(C.Structure):
         return d
 
 
+class TableInfo(C.Structure):
+    """rt_table_info (include/rtmi.h): the device tables the host builds for a scene."""
+    _fields_ = [
+        ("image_floats", C.c_int32), ("grid_wide", C.c_int32), ("grid_sheet", C.c_int32), ("grid_cells", C.c_int32),
+        ("grid_n", C.c_int32 * 3), ("grid_min", C.c_float * 3), ("grid_size", C.c_float * 3),
+        ("ob_near2", C.c_float), ("ob_far2", C.c_float),
+        ("ns", C.c_int32), ("np", C.c_int32), ("ncl", C.c_int32), ("nr", C.c_int32), ("nc", C.c_int32), ("nt", C.c_int32),
+        ("nr_a", C.c_int32), ("nc_a", C.c_int32), ("nt_a", C.c_int32),
+        ("off_grid_cells", C.c_int32), ("off_grid_items", C.c_int32),
+        ("off_sph_cold", C.c_int32), ("off_rect_cold", C.c_int32), ("off_cyl_cold", C.c_int32), ("off_tri_cold", C.c_int32),
+        ("off_rect_hot", C.c_int32), ("off_cyl_hot", C.c_int32), ("off_tri_hot", C.c_int32),
+        ("hot_bytes_grid", C.c_int32), ("kernel_variant", C.c_int32),
+    ]
+
+
 def _sig(name, restype, *argtypes):
     fn = getattr(_lib, name)
     fn.restype = restype
@@ -175,6 +190,8 @@ _sig("rt_tiles_shutdown", None)
 _sig("rt_shard_place_rows_device", C.c_int, _p, C.POINTER(Opts), C.c_int, C.c_int, _p, _p, _p)
 _sig("rt_scene_set_russian_roulette", C.c_int, _p, C.c_float)
 _sig("rt_render_hip_count", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
+_sig("rt_scene_table_info", C.c_int, _p, C.POINTER(TableInfo))
+_sig("rt_scene_table_image", C.c_int, _p, _p, C.c_int)
 _sig("rt_render_hip_accumulate", C.c_int, _p, C.POINTER(Opts), _p, _p, C.POINTER(Stats))
 _sig("rt_acc_to_rgb", None, _p, _p, C.c_size_t)
 _sig("rt_shard_scatter_rows", C.c_int, _p, C.POINTER(Opts), _p, _p)
@@ -188,6 +205,7 @@ _sig("rt_sample_stream", None, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c
 
 C_SYMBOLS = [
     "rt_last_error", "rt_status_string", "rt_abi_version", "rt_struct_size", "rt_device_count", "rt_has_ablations", "rt_opts_default",
+    "rt_scene_table_info", "rt_scene_table_image",
     "rt_scene_load_json", "rt_scene_parse_json", "rt_scene_rtiow", "rt_scene_to_json", "rt_scene_free",
     "rt_scene_new", "rt_scene_set_background", "rt_scene_set_camera", "rt_scene_add_solid_color",
     "rt_scene_add_checker", "rt_scene_add_lambertian", "rt_scene_add_metal", "rt_scene_add_dielectric",
@@ -462,6 +480,21 @@ class Scene:
         """Render into a device buffer (e.g. a torch tensor's data_ptr()) on a HIP stream."""
         _check(_lib.rt_render_hip_device(self._h, C.byref(opts), C.c_void_p(device_ptr), C.c_void_p(stream),
                                          C.byref(stats) if stats is not None else None), "rt_render_hip_device")
+
+    def table_info(self) -> TableInfo:
+        """The device tables the host builds for this scene (no GPU needed)."""
+        t = TableInfo()
+        _check(_lib.rt_scene_table_info(self._h, C.byref(t)), "rt_scene_table_info")
+        return t
+
+    def table_image(self) -> np.ndarray:
+        """The packed device image as float32 records [n][4] (view it as uint32 / uint16 for the index tables)."""
+        n = _lib.rt_scene_table_image(self._h, None, 0)
+        if n < 0:
+            raise RtmiError(-n, "rt_scene_table_image")
+        out = np.empty(n, dtype=np.float32)
+        _lib.rt_scene_table_image(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out.reshape(-1, 4)
 
     def count(self, opts: Opts | None = None, want_image=False):
         """Diagnostic launch with exact event counters (roofline flops accounting)."""

@@ -46,6 +46,7 @@ size_t rt_struct_size(int which) {
     case 4: return sizeof(rt_texture);
     case 5: return sizeof(rt_camera);
     case 6: return sizeof(rt_scene_info);
+    case 7: return sizeof(rt_table_info);
     default: return 0;
     }
 }

@@ -921,6 +921,60 @@ int rt_device_count(void) {
     return n;
 }
 
+// what rt_opts.variant = 0 stands for in a scene with these tables
+static unsigned pick_variant(const RenderParams &P, bool counting, size_t lds_table_bytes) {
+    if (!P.grid_wide) return P.grid_sheet ? 2u : 6u;
+    const size_t grid_bytes = (size_t)P.hot_vec4_grid * 16, scan_bytes = (size_t)(P.hot_vec4 - (P.off_box - P.off_grid)) * 16;
+    // a handful of primitives of several types, none of them listed in a grid: the plain scan is the same search without
+    // the per-query set-up (sample_scene.json: 54 against 79 ms)
+    if (P.grid_cells == 0 && P.ncl == 0 && !counting && scan_bytes <= lds_table_bytes) return 16u;
+    return grid_bytes <= lds_table_bytes ? 36u : 44u;
+}
+
+int rt_scene_table_info(const rt_scene *sc, rt_table_info *out) {
+    if (!sc || !out) {
+        set_error("rt_scene_table_info: null argument");
+        return RT_ERR_ARG;
+    }
+    int rc = scene_validate(sc->s);
+    if (rc) return rc;
+    Scene &ms = const_cast<Scene &>(sc->s);
+    if (!ms.dev) ms.dev = std::make_shared<DeviceSceneCache>();
+    DeviceSceneCache &cache = *ms.dev;
+    std::lock_guard<std::mutex> lock(cache.mu);
+    if (cache.packed_version != sc->s.version) pack_scene(sc->s, cache);
+    const RenderParams &L = cache.layout;
+    memset(out, 0, sizeof *out);
+    out->image_floats = (int32_t)cache.image.size();
+    out->grid_wide = L.grid_wide, out->grid_sheet = L.grid_sheet, out->grid_cells = L.grid_cells;
+    const float *g = cache.image.data() + (size_t)L.off_grid * 4;
+    for (int a = 0; a < 3; ++a) {
+        out->grid_min[a] = g[a], out->grid_size[a] = g[8 + a];
+        memcpy(&out->grid_n[a], g + 12 + a, 4);
+    }
+    out->ob_near2 = g[3], out->ob_far2 = g[7];
+    out->ns = L.ns, out->np = L.np, out->ncl = L.ncl;
+    out->nr = L.nr, out->nc = L.nc, out->nt = L.nt, out->nr_a = L.nr_a, out->nc_a = L.nc_a, out->nt_a = L.nt_a;
+    out->off_grid_cells = L.off_grid_cells, out->off_grid_items = L.off_grid_items;
+    out->off_sph_cold = L.off_sph_cold, out->off_rect_cold = L.off_rect_cold, out->off_cyl_cold = L.off_cyl_cold, out->off_tri_cold = L.off_tri_cold;
+    out->off_rect_hot = L.off_rect_hot, out->off_cyl_hot = L.off_cyl_hot, out->off_tri_hot = L.off_tri_hot;
+    out->hot_bytes_grid = L.hot_vec4_grid * 16;
+    out->kernel_variant = (int32_t)pick_variant(L, false, (size_t)knob("RTMI_GLOBAL_TABLE_BYTES", (double)kLdsTableBytes));
+    return RT_OK;
+}
+
+int rt_scene_table_image(const rt_scene *sc, float *dst, int cap_floats) {
+    rt_table_info info;
+    int rc = rt_scene_table_info(sc, &info);
+    if (rc) return -rc;
+    if (dst && cap_floats > 0) {
+        DeviceSceneCache &cache = *const_cast<Scene &>(sc->s).dev;
+        std::lock_guard<std::mutex> lock(cache.mu);
+        memcpy(dst, cache.image.data(), sizeof(float) * (size_t)std::min(cap_floats, info.image_floats));
+    }
+    return info.image_floats;
+}
+
 static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, void *stream_v, rt_stats *stats,
                        long long *h_acc, bool count) {
     if (!sc || (!d_rgb_sum && !h_acc)) {
@@ -1123,13 +1177,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     };
     static const size_t global_threshold = (size_t)knob("RTMI_GLOBAL_TABLE_BYTES", (double)kLdsTableBytes);
     const bool sphere_only = P.nr + P.nc + P.nt == 0 && !ext;
-    auto pick = [&](bool counting) -> unsigned {  // what variant 0 stands for in this scene
-        if (!P.grid_wide) return P.grid_sheet ? 2u : 6u;
-        // a handful of primitives of several types, none of them listed in a grid: the plain scan is the same search without
-        // the per-query set-up (sample_scene.json: 54 against 79 ms)
-        if (P.grid_cells == 0 && P.ncl == 0 && !counting && hot_bytes_of(16) <= global_threshold) return 16u;
-        return hot_bytes_of(36) <= global_threshold ? 36u : 44u;
-    };
+    auto pick = [&](bool counting) -> unsigned { return pick_variant(P, counting, global_threshold); };
     if (variant == 0) variant = pick(count);
     // the counting kernels exist for the grid walks (3-D) and two ablation searches: anything else is counted by the kernel
     // variant 0 would run (reported in stats->kernel_variant / cull_mode)
