@@ -293,9 +293,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     int c_hy = 0, c_hvalid = 0;  // this lane's home pixel in the current item (row, on-image)
     unsigned long long c_hvmask = 0ull;  // ... and the on-image bits of all 64 home pixels (wave-uniform)
     int mine = 0;                // !POOL: samples of the home pixel started so far (current item)
-    // where this lane's live path adds its sample: -2 the current item's accumulator; >= 0 the path
-    // outlived its item (an orphan): dense local pixel index for a direct global add
-    int slot = -2;
 
     // home pixel of this lane in the tile (x0, band): column, dense local row, image row, on-image
     // item-level launch values, read where they are needed (device_scene.h, ItemParams): wave-uniform
@@ -354,7 +351,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
     //  or loses the roulette contributes exactly zero: nothing to add)
     float beta_r = 1, beta_g = 1, beta_b = 1;
     int depth = 0;
-    int cur_p = lane;  // tile-local pixel of the path this lane is tracing
+    // where this lane's live path adds its sample: >= 0 the tile-local pixel (0 .. 63) in the current item's accumulator; < 0 the
+    // path outlived its item (an orphan): ~cur_p is its dense local pixel index for a direct global add
+    int cur_p = lane;
     bool active = false;
 
     // One iteration of the main loop:
@@ -1241,8 +1240,8 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         if (path_done) {
             {
                 const unsigned long long fr = radiance_to_fixed(L_r), fg = radiance_to_fixed(L_g), fb = radiance_to_fixed(L_b);
-                if (slot >= 0) {
-                    unsigned long long *g = acc + (size_t)slot * 3;
+                if (cur_p < 0) {
+                    unsigned long long *g = acc + (size_t)(~cur_p) * 3;
                     if (fr) atomicAdd(g + 0, fr);
                     if (fg) atomicAdd(g + 1, fg);
                     if (fb) atomicAdd(g + 2, fb);
@@ -1278,7 +1277,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         bool fetch = exhausted && !queue_empty;
         if (c_valid && idle != 0ull && fetch) {
             if (mask_count(~idle) <= P.orphan_max) {
-                if (active && slot == -2) slot = (c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7);
+                if (active && cur_p >= 0) cur_p = ~((c_band * 8 + (cur_p >> 3)) * P.width + c_x0 + (cur_p & 7));
                 flush_tile(c_acc, c_x0, c_band);
                 c_valid = false;
             } else {
@@ -1351,7 +1350,6 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
             }
             if (start) {
                 cur_p = sp;
-                slot = -2;
                 rng_start(rng, (uint32_t)(spy * P.width + spx), (uint32_t)ss, k0, k1);
                 u = ((float)spx + rng_next<COUNT>(rng)) * P.inv_wm1;
                 v = ((float)spy + rng_next<COUNT>(rng)) * P.inv_hm1;
