@@ -1015,12 +1015,15 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // wall time (seven waves share a SIMD) and an item over glass and dense spheres several times the average,
     // so the runs of shorter items have to last long enough for the other waves to have something to do
     // meanwhile.  How many big chunks are given up follows from r = resident waves / tiles: a whole 1080p
-    // frame (r = 0.22) gives up three of sixteen, a 1/8 row shard (r = 1.8) all sixteen, of which 22
+    // frame (r = 0.22) gives up two of sixteen, a 1/8 row shard (r = 1.8) thirteen, of which 13
     // quarter chunks are cut into 4-sample items.  Short items cost little since stragglers no longer
     // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
     // (knob(): measurement knobs of the default build, constants in a product build)
     static const int tail_mode = (int)knob("RTMI_TAIL_MODE", 1);  // 0 = one run of equal chunks
-    static const double tail_factor = knob("RTMI_TAIL_FACTOR", 12.0);  // measured at 7 waves/SIMD: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms, a 1/8 shard 33.7 / 33.4 / 32.0 / 32.2 ms
+    // (round 2: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms.  Round 3, four times as many items, RTIOW 1080p x 1024 spp
+    //  (tools/gpu_tail_sweep.py): 5 / 6 / 7 / 8 / 12 -> rank 0's 1/8 shard 16.70 / 16.32 / 16.34 / 16.41 / 16.53 ms, a 1/4 shard 31.62 /
+    //  31.21 / 31.42 / 31.49 / 31.63, the whole frame within 0.2 %; at 4 and below the last big items outlast the short ones: 17.7 ms)
+    static const double tail_factor = knob("RTMI_TAIL_FACTOR", 7.0);
     static const int tail_div = std::max(2, (int)knob("RTMI_TAIL_DIV", 4));  // big : medium item length
     static const int orphan_env = (int)knob("RTMI_ORPHAN_MAX", -1);
     int n_big = sample_count / spp_chunk, n_med = 0, q_med = spp_chunk, q_small = spp_chunk;
