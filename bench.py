@@ -166,6 +166,7 @@ def main():
     scene = rtmi.Scene.rtiow(7, args.width, args.height, args.spp, args.depth)
     chunk = args.chunk if args.chunk >= 0 else 0  # 0 = the library's default work-item size
     base = rtmi.Opts(seed=args.seed, device=dev_index, tile_rows=args.tile_rows, spp_chunk=chunk, variant=args.variant)
+    base.tile_rotate = scene.shard_deal(base, world)  # how the frame's row tiles are dealt out to the ranks (include/rtmi.h)
     mine = rdist.shard_opts(base, rank, world)
     local = rdist.alloc_local(scene, base, world, device)
     full = torch.empty((scene.height, scene.width, 3), dtype=torch.float32, device=device) if rank == 0 else None

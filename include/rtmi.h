@@ -269,11 +269,15 @@ typedef struct rt_opts {
     int32_t tile_rows;   /* 0 -> 8                                             */
     int32_t tile_first;
     int32_t tile_stride;
-    /* 1: ROTATED interleave -- of every group of tile_stride consecutive tiles the shard tile_first owns one, and which one
-     * rotates from group to group: its k-th tile is k * tile_stride + ((tile_first - k) mod tile_stride), i.e. tile t
-     * belongs to shard (t + t / tile_stride) mod tile_stride.  Same number of tiles per shard as the plain interleave,
-     * but no shard keeps one row phase of the image for itself (RTIOW 1080p over 8 shards: the shards' work differs by
-     * +-0.4 % instead of +-1.8 %).  rt_render_hip_tiles and bench.py split frames this way.  0: the plain interleave above. */
+    /* How the tiles are dealt out to the tile_stride shards (N = tile_stride).  0: the plain interleave above.
+     * 1: ROTATED interleave -- of every group of N consecutive tiles the shard tile_first owns one, and which one rotates
+     *    from group to group: its k-th tile is k N + ((tile_first - k) mod N), i.e. tile t belongs to shard (t + t / N) mod N:
+     *    no shard keeps one row phase of the image for itself.
+     * 2: THERE AND BACK -- groups of 2 N tiles go to shards 0 .. N-1, then N-1 .. 0: the shard's tiles are 2 N j + tile_first and
+     *    2 N j + 2 N - 1 - tile_first, which cancels the trend of the cost along the image inside every group.
+     * All three give every shard the same number of tiles (+-1).  rt_shard_deal() says which one rt_render_hip_tiles and
+     * bench.py use for a frame: 1 when the frame has >= 4 N^2 tiles (the rotation has gone round four times), else 2
+     * (RTIOW 1080p, 135 tiles, busiest shard above the mean: N = 4: 0.36 % / 0.86 %, N = 8: 2.17 % / 0.92 % for 1 / 2). */
     int32_t tile_rotate;
     /* samples per work item (one wave renders an 8x8 tile x spp_chunk samples at a time).
      * Scheduling only: the per-pixel sum is exact (64-bit fixed point, 2^-24), so the
@@ -343,6 +347,9 @@ void rt_opts_default(rt_opts *o);
  * local row r <-> global row rt_shard_row(...)). */
 int rt_shard_rows(const rt_scene *s, const rt_opts *o);
 int rt_shard_global_row(const rt_scene *s, const rt_opts *o, int local_row);
+/* the value of rt_opts.tile_rotate that rt_render_hip_tiles uses to cut this frame (o: tile_rows) into n_ranks shards
+ * (blue.py:23-32 deals whole frames to GPUs; here the tiles of one frame) */
+int rt_shard_deal(const rt_scene *s, const rt_opts *o, int n_ranks);
 
 /* render<<<grid, 8x8>>>(spp, background, cam, world, max_depth, W, H, image, states)
  * gpu-version/main.cu:72-105 with its launch at :505-507.
@@ -401,8 +408,8 @@ int rt_shard_scatter_rows(const rt_scene *s, const rt_opts *o, const float *loca
                           float *full_rgb);
 
 /* the same on the device, for a GATHERED buffer: d_gathered[n_ranks][pad_rows][W][3] holds rank r's dense local
- * rows (tile t of the frame = local tile t / n_ranks of rank t mod n_ranks, or of rank (t + t / n_ranks) mod n_ranks
- * when o->tile_rotate is set: how the shards were cut; pad_rows >= the largest shard), as
+ * rows (o->tile_rotate says how the shards were cut -- which rank owns tile t of the frame and as which of its
+ * local tiles; pad_rows >= the largest shard), as
  * ncclGather delivers them; one kernel on `stream` (hipStream_t as void*) writes d_full[H][W][3].
  * rt_render_hip_tiles uses it on its root device. */
 int rt_shard_place_rows_device(const rt_scene *s, const rt_opts *o, int n_ranks, int pad_rows,

@@ -183,6 +183,7 @@ _sig("rt_scene_get_materials", C.c_int, _p, _p, C.c_int)
 _sig("rt_scene_get_textures", C.c_int, _p, _p, C.c_int)
 _sig("rt_shard_rows", C.c_int, _p, C.POINTER(Opts))
 _sig("rt_shard_global_row", C.c_int, _p, C.POINTER(Opts), C.c_int)
+_sig("rt_shard_deal", C.c_int, _p, C.POINTER(Opts), C.c_int)
 _sig("rt_render_hip_device", C.c_int, _p, C.POINTER(Opts), _p, _p, C.POINTER(Stats))
 _sig("rt_render_hip", C.c_int, _p, C.POINTER(Opts), _p, C.POINTER(Stats))
 _sig("rt_render_hip_tiles", C.c_int, _p, C.POINTER(Opts), C.POINTER(C.c_int), C.c_int, _p, C.POINTER(Stats))
@@ -213,7 +214,7 @@ C_SYMBOLS = [
     "rt_scene_add_image_texture", "rt_scene_add_image_texture_file", "rt_scene_get_image", "rt_scene_add_triangle",
     "rt_scene_add_obj",
     "rt_scene_override", "rt_scene_get_info", "rt_scene_get_camera", "rt_scene_get_prims",
-    "rt_scene_get_materials", "rt_scene_get_textures", "rt_shard_rows", "rt_shard_global_row",
+    "rt_scene_get_materials", "rt_scene_get_textures", "rt_shard_rows", "rt_shard_global_row", "rt_shard_deal",
     "rt_render_hip_device", "rt_render_hip", "rt_render_hip_tiles", "rt_tiles_shutdown", "rt_shard_place_rows_device", "rt_render_hip_count", "rt_render_hip_accumulate", "rt_scene_set_russian_roulette",
     "rt_acc_to_rgb", "rt_shard_scatter_rows", "rt_write_ppm",
     "rt_quantize_rgb8", "rt_philox4x32_10", "rt_aabb_hit", "rt_sample_stream", "rt_write_png",
@@ -440,6 +441,11 @@ class Scene:
     def shard_rows(self, opts: Opts | None = None) -> int:
         opts = opts or Opts()
         return _check_id(_lib.rt_shard_rows(self._h, C.byref(opts)), "rt_shard_rows")
+
+    def shard_deal(self, opts: Opts | None, n_ranks: int) -> int:
+        """rt_opts.tile_rotate that rt_render_hip_tiles uses to cut this frame into n_ranks shards (rt_shard_deal)."""
+        opts = opts or Opts()
+        return _check_id(_lib.rt_shard_deal(self._h, C.byref(opts), n_ranks), "rt_shard_deal")
 
     def shard_global_rows(self, opts: Opts | None = None) -> np.ndarray:
         opts = opts or Opts()

@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(const Re
         hlr = band * 8 + (lane >> 3);
         const int htl = hlr / tile_rows;
         int tile = tile_first + htl * tile_stride;
-        if (tile_rotate) {  // rotated interleave (include/rtmi.h, rt_opts.tile_rotate)
+        if (tile_rotate == 2) {  // there and back (include/rtmi.h, rt_opts.tile_rotate)
+            tile = (htl >> 1) * 2 * tile_stride + ((htl & 1) ? 2 * tile_stride - 1 - tile_first : tile_first);
+        } else if (tile_rotate) {  // rotated interleave
             int j = (tile_first - htl) % tile_stride;
             if (j < 0) j += tile_stride;
             tile = htl * tile_stride + j;

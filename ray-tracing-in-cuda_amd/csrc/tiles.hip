@@ -79,9 +79,9 @@ static RcclApi *rccl_api() {
         }                                                                                                               \
     } while (0)
 
-// gathered[rank][pad_rows][W][3] (each rank's local rows dense, tile t of the frame = local tile t / N of rank
-// (t + t / N) mod N: the rotated interleave of rt_opts.tile_rotate)  ->  full[H][W][3].  One thread per float;
-// consecutive threads read and write consecutive floats.
+// gathered[rank][pad_rows][W][3] (each rank's local rows dense; which rank owns tile t of the frame, and as which of its
+// local tiles, follows rt_opts.tile_rotate: 0 plain interleave, 1 rotated, 2 there and back)  ->  full[H][W][3].  One thread
+// per float; consecutive threads read and write consecutive floats.
 __global__ __launch_bounds__(256) void place_rows_kernel(const float *__restrict__ gathered, float *__restrict__ full,
                                                          int height, int row_floats, int tile_rows, int n_ranks,
                                                          int pad_rows, int rotate) {
@@ -91,8 +91,15 @@ __global__ __launch_bounds__(256) void place_rows_kernel(const float *__restrict
     const int y = (int)(i / row_floats);
     const int c = (int)(i - (size_t)y * row_floats);
     const int t = y / tile_rows;
-    const int rank = rotate ? (t % n_ranks + t / n_ranks) % n_ranks : t % n_ranks;
-    const int local_row = (t / n_ranks) * tile_rows + (y - t * tile_rows);
+    int rank = t % n_ranks, local_tile = t / n_ranks;
+    if (rotate == 1) {
+        rank = (t % n_ranks + t / n_ranks) % n_ranks;
+    } else if (rotate == 2) {
+        const int p = t % (2 * n_ranks), back = p >= n_ranks ? 1 : 0;
+        rank = back ? 2 * n_ranks - 1 - p : p;
+        local_tile = 2 * (t / (2 * n_ranks)) + back;
+    }
+    const int local_row = local_tile * tile_rows + (y - t * tile_rows);
     full[i] = gathered[((size_t)rank * pad_rows + local_row) * row_floats + c];
 }
 
@@ -226,7 +233,7 @@ extern "C" int rt_render_hip_tiles(const rt_scene *sc, const rt_opts *o, const i
         shard[r].device = devs[r];
         shard[r].tile_first = r;
         shard[r].tile_stride = N;
-        shard[r].tile_rotate = N > 1 ? 1 : 0;
+        shard[r].tile_rotate = rt_shard_deal(sc, &base, N);
         const int rows = rt_shard_rows(sc, &shard[r]);
         if (rows < 0) return -rows;
         pad_rows = std::max(pad_rows, rows);
@@ -355,7 +362,11 @@ extern "C" int rt_shard_place_rows_device(const rt_scene *sc, const rt_opts *o, 
         return RT_ERR_ARG;
     }
     const int tile_rows = (o && o->tile_rows > 0) ? o->tile_rows : 8;
-    const int rotate = (o && o->tile_rotate && n_ranks > 1) ? 1 : 0;  // how the ranks' shards were cut (rt_opts.tile_rotate)
+    const int rotate = (o && n_ranks > 1) ? o->tile_rotate : 0;  // how the ranks' shards were cut (rt_opts.tile_rotate)
+    if (rotate < 0 || rotate > 2) {
+        set_error("rt_shard_place_rows_device: tile_rotate %d", rotate);
+        return RT_ERR_ARG;
+    }
     const int W = sc->s.width, H = sc->s.height;
     const int tiles = (H + tile_rows - 1) / tile_rows;
     const int need = ((tiles + n_ranks - 1) / n_ranks) * tile_rows;  // rows of the largest shard, rounded up to whole tiles

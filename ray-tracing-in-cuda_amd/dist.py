@@ -19,14 +19,21 @@ import torch.distributed as dist
 from . import Opts
 
 
-def shard_opts(base: Opts, rank: int, world: int) -> Opts:
-    """rt_opts of one rank: interleaved row tiles rank, rank+world, ..."""
+def shard_opts(base: Opts, rank: int, world: int, deal: int | None = None) -> Opts:
+    """rt_opts of one rank: its share of the frame's row tiles.  `deal` = rt_opts.tile_rotate (include/rtmi.h: 0 plain
+    interleave, 1 rotated, 2 there and back); None keeps base.tile_rotate when it is set, else the rotated interleave --
+    callers that know the scene pass scene.shard_deal(base, world), what rt_render_hip_tiles uses."""
     o = Opts()
     for name, _ in Opts._fields_:
         setattr(o, name, getattr(base, name))
     o.tile_first = rank
     o.tile_stride = world
-    o.tile_rotate = 1 if world > 1 else 0  # rotated interleave: no rank keeps one row phase of the image (include/rtmi.h)
+    if world <= 1:
+        o.tile_rotate = 0
+    elif deal is not None:
+        o.tile_rotate = deal
+    elif not base.tile_rotate:
+        o.tile_rotate = 1
     return o
 
 

@@ -103,7 +103,7 @@ def test_partition_invariance(rtmi, scenes_dir, golden_dir, world, tile_rows):
     sc.override(width=72, height=45, spp=4)
     full = sc.render(rtmi.Opts(seed=SEED))
     out = np.zeros_like(full)
-    for rotate in (0, 1):  # the plain and the rotated interleave (rt_opts.tile_rotate)
+    for rotate in (0, 1, 2):  # plain interleave, rotated, there and back (rt_opts.tile_rotate)
         out[:] = 0
         for r in range(world):
             o = rtmi.Opts(seed=SEED, tile_rows=tile_rows, tile_first=r, tile_stride=world, tile_rotate=rotate)

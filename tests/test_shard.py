@@ -39,6 +39,25 @@ def test_shard_geometry(rtmi, scenes_dir):
             allrows += list(rows)
             counts.append(len(set(t)))
         assert sorted(allrows) == list(range(45)) and max(counts) - min(counts) <= 1
+    # there and back (tile_rotate = 2): groups of 2 * world tiles go to ranks 0 .. world-1, then world-1 .. 0
+    for world in (2, 3, 4, 8):
+        allrows, counts = [], []
+        for r in range(world):
+            o = rtmi.Opts(tile_first=r, tile_stride=world, tile_rotate=2)
+            rows = sc.shard_global_rows(o)
+            t = np.asarray(rows) // 8
+            p = t % (2 * world)
+            assert np.array_equal(np.where(p < world, p, 2 * world - 1 - p), np.full(len(rows), r))
+            assert list(rows) == sorted(rows) and sc.shard_rows(o) == len(rows)
+            allrows += list(rows)
+            counts.append(len(set(t)))
+        assert sorted(allrows) == list(range(45)) and max(counts) - min(counts) <= 1
+    with pytest.raises(rtmi.RtmiError):
+        sc.shard_rows(rtmi.Opts(tile_first=0, tile_stride=2, tile_rotate=3))
+    # which deal rt_render_hip_tiles and bench.py use: rotated once the frame has 4 N^2 tiles, else there and back
+    big = rtmi.Scene.rtiow(7, 64, 1080, 1, 5)
+    assert [big.shard_deal(None, n) for n in (1, 2, 4, 8)] == [0, 1, 1, 2]
+    assert sc.shard_deal(rtmi.Opts(tile_rows=1), 3) == 1 and sc.shard_deal(None, 3) == 2   # 45 rows: 45 tiles of 1 row, 6 of 8
     # tile_rows other than 8, partial last tile
     rows = sc.shard_global_rows(rtmi.Opts(tile_rows=16, tile_first=1, tile_stride=2))
     assert list(rows) == list(range(16, 32))

@@ -46,8 +46,18 @@ def test_tiles_argument_errors(rtmi):
             sc.render_tiles([0, 0])
 
 
+def _owner(t, world, rotate):
+    """rank of row tile t (include/rtmi.h, rt_opts.tile_rotate)"""
+    if rotate == 1:
+        return (t + t // world) % world
+    if rotate == 2:
+        p = t % (2 * world)
+        return np.where(p < world, p, 2 * world - 1 - p)
+    return t % world
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("rotate", [1, 0])
+@pytest.mark.parametrize("rotate", [2, 1, 0])
 @pytest.mark.parametrize("world,tile_rows,h", [(2, 8, 54), (3, 8, 45), (8, 8, 1080 // 4), (5, 16, 77), (8, 4, 30)])
 def test_gathered_layout_placement_kernel(rtmi, world, tile_rows, h, rotate):
     """What the root does after the gather, for N > 1: shards laid out [rank][pad_rows][W][3] -> the frame.  rotate = 1 is
@@ -62,7 +72,7 @@ def test_gathered_layout_placement_kernel(rtmi, world, tile_rows, h, rotate):
         assert (owners[rows] == -1).all()
         owners[rows] = r
         t = np.asarray(rows) // tile_rows
-        assert np.array_equal((t + t // world) % world if rotate else t % world, np.full(len(rows), r))
+        assert np.array_equal(_owner(t, world, rotate), np.full(len(rows), r))
     assert (owners >= 0).all()
     pad = max(sc.shard_rows(o) for o in shards)
     gathered = torch.full((world, pad, 120, 3), float("nan"), dtype=torch.float32, device="cuda:0")

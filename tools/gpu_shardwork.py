@@ -1,5 +1,5 @@
 """Work share against time share of the 1/N row-tile shards (run on the GPU box): exact query counts of the diagnostic
-kernel, kernel time of the product kernel.  usage: gpu_shardwork.py [N] [spp] [spp_chunk] [rotate: 1 (default, what bench.py and rt_render_hip_tiles use) | 0]"""
+kernel, kernel time of the product kernel.  usage: gpu_shardwork.py [N] [spp] [spp_chunk] [deal: rt_opts.tile_rotate 0 | 1 | 2; default: what bench.py and rt_render_hip_tiles use, rt_shard_deal]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,8 +8,9 @@ rtmi = load_package()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-rotate = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 sc = rtmi.Scene.rtiow(7, 1920, 1080, spp, 50)
+rotate = int(sys.argv[4]) if len(sys.argv) > 4 else sc.shard_deal(None, N)
+print(f"deal {rotate}", flush=True)
 def best(o, n=4):
     sc.render(o)
     ts = []
