@@ -100,6 +100,8 @@ def parse_args(argv=None):
     ap.add_argument("--verify", action="store_true", help="rank 0 also renders the unsharded frame and checks the "
                     "gathered one against it bit for bit (outside the timed region)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal: ranks may share one GPU)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: every step waits for its own gather (default: a frame's "
+                    "gather overlaps the next frame's render)")
     ap.add_argument("--tiles-abi", action="store_true", help="one process: rt_render_hip_tiles (C ABI) over --gpus N devices")
     return ap.parse_args(argv)
 
@@ -168,21 +170,41 @@ def main():
     base = rtmi.Opts(seed=args.seed, device=dev_index, tile_rows=args.tile_rows, spp_chunk=chunk, variant=args.variant)
     base.tile_rotate = scene.shard_deal(base, world)  # how the frame's row tiles are dealt out to the ranks (include/rtmi.h)
     mine = rdist.shard_opts(base, rank, world)
-    local = rdist.alloc_local(scene, base, world, device)
+    # N > 1: two local buffers, so that the gather of one frame travels while the next frame renders (the collective runs on
+    # the communicator's own stream; a frame is placed on rank 0 one step after it was rendered, the last one before the
+    # closing barrier of whatever region the steps are in).  --no-overlap: one buffer, every step waits for its gather.
+    overlap = world > 1 and not args.no_overlap
+    locals_ = [rdist.alloc_local(scene, base, world, device) for _ in range(2 if overlap else 1)]
+    local = locals_[0]
     full = torch.empty((scene.height, scene.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
     stream = torch.cuda.current_stream().cuda_stream
     via_host = args.backend != "nccl"
+    in_flight = []   # at most one PendingGather
+    n_steps = [0]
+
+    def finish_gather():
+        img = None
+        while in_flight:
+            img = rdist.gather_end(in_flight.pop(0), scene, base, rank, world, local.shape[0], device, out=full, via_host=via_host)
+        return img
 
     def step(events=None):
         # HIP events on the stream the kernels are launched on; read after the timed loop (no host wait here)
+        buf = locals_[n_steps[0] % len(locals_)]
+        n_steps[0] += 1
         if events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        scene.render_device(mine, local.data_ptr(), stream, None)
+        scene.render_device(mine, buf.data_ptr(), stream, None)
         if events is not None:
             e1.record()
             events.append((e0, e1))
-        return rdist.gather_framebuffer(local, scene, base, rank, world, out=full, via_host=via_host)
+        if not overlap:
+            return rdist.gather_framebuffer(buf, scene, base, rank, world, out=full, via_host=via_host)
+        started = rdist.gather_begin(buf, rank, world, via_host=via_host, slot=(n_steps[0] - 1) % 2)
+        img = finish_gather()  # the previous frame: its buffer is free again once this returns
+        in_flight.append(started)
+        return img
 
     def barrier():
         if world > 1:
@@ -194,15 +216,19 @@ def main():
     # every render_kernel row of a `rocprofv3 --stats` summary of this command is one step's launch.
     with stdout_to_stderr():
         step()
+        finish_gather()
         if world > 1:
             dist.barrier()
     for _ in range(args.warmup):
         step()
+    finish_gather()
     barrier()
     events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = step(events)
+    if overlap:
+        img = finish_gather()  # the last frame's gather and placement belong to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -234,8 +260,9 @@ def main():
         "config": {
             "workload": f"RTIOW random-spheres scene (rt_scene_rtiow seed 7, {scene.info.num_prims} spheres), "
                         f"{scene.width}x{scene.height}, {scene.spp} spp, depth {scene.max_depth}",
-            "sharding": f"row tiles of {args.tile_rows} rows interleaved over {world} rank(s), one gather to rank 0 "
-                        f"({args.backend})",
+            "sharding": f"row tiles of {args.tile_rows} rows dealt out to {world} rank(s) (rt_opts.tile_rotate = {base.tile_rotate}), "
+                        f"one gather to rank 0 per frame ({args.backend}"
+                        + (", overlapping the next frame's render)" if overlap else ")"),
             "spp_chunk": chunk,
             "kernel_variant": args.variant,
             "render_seed": args.seed,

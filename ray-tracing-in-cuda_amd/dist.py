@@ -77,11 +77,45 @@ def gather_framebuffer(local: torch.Tensor, scene, base: Opts, rank: int, world:
     return full
 
 
+class PendingGather:
+    """A gather that has been started (gather_begin) and not yet placed (gather_end)."""
+    __slots__ = ("work", "big", "send")
+
+    def __init__(self, work, big, send):
+        self.work, self.big, self.send = work, big, send
+
+
+def gather_begin(local: torch.Tensor, rank: int, world: int, dst: int = 0, group=None, via_host: bool = False,
+                 slot: int = 0) -> PendingGather:
+    """First half of gather_framebuffer for world > 1: start the gather of `local` and return without making the current
+    stream wait for it, so that the caller's next launch (the next frame, rendered into ANOTHER local buffer) overlaps the
+    transfer.  `slot` selects the root's receive buffer: frames in flight at the same time need different slots."""
+    send = local.cpu() if via_host else local
+    big = _recv_buffer(send, world, slot) if rank == dst else None
+    parts = list(big.unbind(0)) if big is not None else None
+    work = dist.gather(send, gather_list=parts, dst=dst, group=group, async_op=True)
+    return PendingGather(work, big, send)
+
+
+def gather_end(p: PendingGather, scene, base: Opts, rank: int, world: int, padded_rows: int, device, dst: int = 0,
+               out: torch.Tensor | None = None, via_host: bool = False):
+    """Second half: wait for the gather (the current stream waits, not the host, for nccl) and place the rows on dst.
+    After it the local buffer the gather read may be written again."""
+    p.work.wait()
+    if rank != dst:
+        return None
+    big = p.big.to(device, non_blocking=True) if via_host else p.big
+    full = out if out is not None else torch.empty((scene.height, scene.width, 3), dtype=big.dtype, device=device)
+    src, dst_rows = _gather_indices(scene, base, world, padded_rows, device)
+    full.index_copy_(0, dst_rows, big.view(-1, scene.width, 3).index_select(0, src))
+    return full
+
+
 _RECV_CACHE: dict = {}
 
 
-def _recv_buffer(like: torch.Tensor, world: int) -> torch.Tensor:
-    key = (tuple(like.shape), like.dtype, str(like.device), world)
+def _recv_buffer(like: torch.Tensor, world: int, slot: int = 0) -> torch.Tensor:
+    key = (tuple(like.shape), like.dtype, str(like.device), world, slot)
     t = _RECV_CACHE.get(key)
     if t is None:
         t = torch.empty((world,) + tuple(like.shape), dtype=like.dtype, device=like.device)

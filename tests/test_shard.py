@@ -105,10 +105,32 @@ def _worker(rank, world, port, height, tile_rows, q):
         rows = sc.shard_global_rows(mine)
         local[: len(rows)] = torch.from_numpy(full_ref[rows])
         full = rdist.gather_framebuffer(local, sc, base, rank, world)
+        ok = True
         if rank == 0:
-            q.put(bool(np.array_equal(full.numpy(), full_ref)))
+            ok = bool(np.array_equal(full.numpy(), full_ref))
         else:
             assert full is None
+        # the two-phase form bench.py pipelines (a frame's gather travels while the next frame renders): two frames in
+        # flight in two local buffers and two receive slots, placed in order; every deal of the tiles (rt_opts.tile_rotate)
+        for deal in (0, 1, 2):
+            b2 = rdist.shard_opts(base, 0, 1)
+            b2.tile_rotate = deal
+            m2 = rdist.shard_opts(b2, rank, world)
+            rows2 = sc.shard_global_rows(m2)
+            bufs = [rdist.alloc_local(sc, b2, world, "cpu") for _ in range(2)]
+            frames = [full_ref, full_ref * 2.0 + 1.0]
+            pend = []
+            for i in range(2):
+                bufs[i][: len(rows2)] = torch.from_numpy(frames[i][rows2])
+                pend.append(rdist.gather_begin(bufs[i], rank, world, slot=i))
+            for i in range(2):
+                got = rdist.gather_end(pend[i], sc, b2, rank, world, bufs[i].shape[0], "cpu")
+                if rank == 0:
+                    ok = ok and bool(np.array_equal(got.numpy(), frames[i]))
+                else:
+                    assert got is None
+        if rank == 0:
+            q.put(ok)
     finally:
         dist.destroy_process_group()
 
