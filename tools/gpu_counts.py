@@ -1,3 +1,4 @@
+"""Diagnostic counters of the bench frame per query: candidate lanes, resolve entries per wave (run on the GPU box).  usage: gpu_counts.py [spp]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
