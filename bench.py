@@ -327,7 +327,7 @@ def tiles_abi_frames(rtmi, scene, base, devices, steps, np, reference=None):
     wall, kern, gath = [], [], []
     for _ in range(steps):
         t0 = time.perf_counter()
-        img = scene.render_tiles(devices=devices, opts=o, stats=st)
+        img = scene.render_tiles(devices=devices, opts=o, stats=st, out=img)  # (the caller's buffer, as a renderer's frame loop has one)
         wall.append((time.perf_counter() - t0) * 1e3)
         kern.append(st.kernel_ms), gath.append(st.gather_ms)
     n = scene.width * scene.height * scene.spp

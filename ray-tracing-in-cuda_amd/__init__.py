@@ -462,9 +462,11 @@ class Scene:
         _check(_lib.rt_render_hip(self._h, C.byref(opts), out.ctypes.data_as(C.c_void_p), C.byref(st)), "rt_render_hip")
         return out
 
-    def render_tiles(self, devices=None, opts: Opts | None = None, stats: Stats | None = None, n: int | None = None):
-        """One frame over several GPUs of this node: row tiles interleaved over `devices` (ordinals; None =
-        0..n-1), one ncclGather to devices[0] (rt_render_hip_tiles).  Returns the (H, W, 3) fp32 sums."""
+    def render_tiles(self, devices=None, opts: Opts | None = None, stats: Stats | None = None, n: int | None = None,
+                     out: np.ndarray | None = None):
+        """One frame over several GPUs of this node: row tiles dealt out to `devices` (ordinals; None =
+        0..n-1), one ncclGather to devices[0] (rt_render_hip_tiles).  Returns the (H, W, 3) fp32 sums (in `out` when given:
+        a C-contiguous float32 array of that shape)."""
         opts = opts or Opts()
         if devices is None:
             count = int(n if n is not None else 1)
@@ -472,7 +474,10 @@ class Scene:
         else:
             count = len(devices)
             arr = (C.c_int * count)(*[int(d) for d in devices])
-        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        if out is None:
+            out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        elif out.shape != (self.height, self.width, 3) or out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("render_tiles: out must be a C-contiguous float32 array of shape (height, width, 3)")
         _check(_lib.rt_render_hip_tiles(self._h, C.byref(opts), arr, count, out.ctypes.data_as(C.c_void_p),
                                         C.byref(stats) if stats is not None else None), "rt_render_hip_tiles")
         return out
