@@ -14,7 +14,9 @@ geometry written down a second time in numpy fp64 from the reference's definitio
 
 An fp32 and an fp64 evaluation may disagree on hit / miss only where the fp64 geometry is within a hair of a boundary (an
 edge, a grazing discriminant, t_min): those rays are set aside by a margin and counted, everything else must agree on hit /
-miss and on t to 2e-5 relative (measured: 2e-6 at worst, no disagreement even among the rays set aside).  No GPU needed; the kernel is held bit-for-bit to the same restatement elsewhere."""
+miss and on t to 2e-5 relative (measured: 2e-6 at worst, no disagreement even among the rays set aside).  The hit record's
+texture coordinates (object.cuh:87-93, 113-114, 283-288; hittable.py:54-58, 233 -- the restatement evaluates atan2 / acos with
+its own fixed operation sequence, shared with the kernel) are compared on the same hits to 1e-5.  No GPU needed; the kernel is held bit-for-bit to the same restatement elsewhere."""
 import numpy as np
 import pytest
 
@@ -31,10 +33,11 @@ def _rays(rng, n, reach=4.0):
 
 def _probe(rtcheck, sc, o, d):
     osc = rtcheck.OracleScene(sc)
-    hit, t = np.zeros(len(o), bool), np.zeros(len(o))
+    hit, t, uv = np.zeros(len(o), bool), np.zeros(len(o)), np.zeros((len(o), 2))
     for i in range(len(o)):
-        h, _, tt, _ = rtcheck.oracle_hit_uv(osc, [float(v) for v in o[i]], [float(v) for v in d[i]])
-        hit[i], t[i] = h, tt
+        h, (u, v), tt, _ = rtcheck.oracle_hit_uv(osc, [float(v) for v in o[i]], [float(v) for v in d[i]])
+        hit[i], t[i], uv[i] = h, tt, (u, v)
+    _probe.uv = uv  # (texture coordinates of the last probe, for _compare_uv)
     return hit, t
 
 
@@ -50,6 +53,16 @@ def _compare(name, hit32, t32, hit64, t64, margin, min_decided=0.8):
     assert rel.max() < 2e-5, (name, rel.max())
     # and the undecided ones are few and, where both say hit, still close
     return int(both.sum()), int((~decided).sum())
+
+
+def _compare_uv(name, judged, u64, v64, period=None, tol=1e-5):
+    """texture coordinates of the judged hits; `period`: u wraps around (the angle's branch cut)"""
+    uv = _probe.uv
+    du = np.abs(uv[judged, 0] - u64[judged])
+    if period:
+        du = np.minimum(du, np.abs(period - du))
+    dv = np.abs(uv[judged, 1] - v64[judged])
+    assert du.max() < tol and dv.max() < tol, (name, du.max(), dv.max())
 
 
 def _scene(rtmi):
@@ -76,6 +89,9 @@ def test_sphere_random_rays(rtmi, rtcheck):
     margin = np.minimum(np.abs(disc) / scale, np.minimum(np.abs(t0 - T_MIN), np.abs(t1 - T_MIN)) / np.maximum(1.0, np.abs(t1)) * 10)
     margin = np.where(disc < 0, np.abs(disc) / scale, margin)
     _compare("sphere", hit32, t32, hit64, t64, margin)
+    n = (o + t64[:, None] * d - c) / r  # outward normal, object.cuh:87-93: u = (atan2(-z, x) + pi) / 2 pi, v = acos(-y) / pi
+    judged = (margin > 2e-3) & hit64
+    _compare_uv("sphere", judged, (np.arctan2(-n[:, 2], n[:, 0]) + np.pi) / (2 * np.pi), np.arccos(np.clip(-n[:, 1], -1, 1)) / np.pi, period=1.0)
 
 
 @pytest.mark.parametrize("axis", [0, 1, 2])
@@ -97,6 +113,7 @@ def test_rect_random_rays(rtmi, rtcheck, axis):
     margin = np.minimum(edge, np.abs(t64 - T_MIN) * 10)
     margin = np.where(np.isfinite(t64), margin, 1.0)
     _compare(f"rect axis {axis}", hit32, t32, hit64, np.nan_to_num(t64), margin)
+    _compare_uv(f"rect axis {axis}", (margin > 2e-3) & hit64, (pa - a0) / (a1 - a0), (pb - b0) / (b1 - b0))
 
 
 def _rodrigues(axis, deg):
@@ -141,13 +158,17 @@ def test_cylinder_random_rays(rtmi, rtcheck, case):
     hits, undecided = _compare(f"cylinder {case}", hit32, t32, hit64, t64, margin, min_decided=0.75)
     # both kinds of hit occur: the near wall from outside and the far wall seen through the open ends / from inside
     assert (hit64 & ok0).sum() > 50 and (hit64 & ~ok0 & ok1).sum() > 20
+    op = oo + t64[:, None] * dd  # object.cuh:283-288: u = (atan2(y, x) + 2 pi) / 4 pi, v = (z - zmin) / (zmax - zmin)
+    _compare_uv(f"cylinder {case}", (margin > 2e-3) & hit64, (np.arctan2(op[:, 1], op[:, 0]) + 2 * np.pi) / (4 * np.pi),
+                (op[:, 2] - zmin) / (zmax - zmin), period=0.5)
 
 
 def test_triangle_random_rays(rtmi, rtcheck):
     rng = np.random.default_rng(40)
     v = np.array([[-0.9, -0.6, 0.1], [1.0, -0.4, -0.3], [0.1, 0.9, 0.4]])
     sc, m = _scene(rtmi)
-    sc.triangle(tuple(v[0]), tuple(v[1]), tuple(v[2]), m)
+    tuv = np.array([[0.1, 0.2], [0.9, 0.3], [0.4, 0.8]])
+    sc.triangle(tuple(v[0]), tuple(v[1]), tuple(v[2]), m, u1=tuple(tuv[0]), u2=tuple(tuv[1]), u3=tuple(tuv[2]))
     o, d = _rays(rng, 4000)
     hit32, t32 = _probe(rtcheck, sc, o, d)
     e1, e2 = v[1] - v[0], v[2] - v[0]
@@ -172,3 +193,8 @@ def test_triangle_random_rays(rtmi, rtcheck):
     hits, _ = _compare("triangle", hit32, t32, hit64, np.nan_to_num(t64), margin, min_decided=0.9)
     # seen from both sides
     assert ((den > 0) & hit64).sum() > 30 and ((den < 0) & hit64).sum() > 30
+    # hittable.py:54-58, 233: the area weights w1 = |a1 x a2| (the sub-triangle opposite v3), w2 = |a1 x a3| (opposite v2),
+    # w3 = |a3 x a2| (opposite v1) multiply u1, u2, u3 IN THAT ORDER -- restated as the reference has it
+    l1, l2, l3 = bw, bu, bv  # barycentric weights of v1, v2, v3
+    _compare_uv("triangle", (margin > 2e-3) & hit64, tuv[0, 0] * l3 + tuv[1, 0] * l2 + tuv[2, 0] * l1,
+                tuv[0, 1] * l3 + tuv[1, 1] * l2 + tuv[2, 1] * l1)
