@@ -198,3 +198,69 @@ def test_triangle_random_rays(rtmi, rtcheck):
     l1, l2, l3 = bw, bu, bv  # barycentric weights of v1, v2, v3
     _compare_uv("triangle", (margin > 2e-3) & hit64, tuv[0, 0] * l3 + tuv[1, 0] * l2 + tuv[2, 0] * l1,
                 tuv[0, 1] * l3 + tuv[1, 1] * l2 + tuv[2, 1] * l1)
+
+
+# ---- the hit record's point and normal, seen through the scatter step -------------------------------------------------------
+# lambertian::scatter (material.h:25-35) sends the next ray from the hit point p along  n + unit_vector  with n the unit normal
+# turned against the incoming ray (set_face_normal, hittable.h:17-20): whatever the random unit vector is, the next query starts
+# at p and |dir - n| = 1.  So the checker's trace of a path (rto_trace_sample: origin and direction of every query) pins p, the
+# direction of n, its sign and its length against the fp64 geometry -- for the primitives whose hit() no reference run covers.
+
+def _normal_check(rtmi, rtcheck, build, normal_at, lookfroms, name, min_hits=300):
+    total = 0
+    for cam in lookfroms:
+        sc = rtmi.Scene.new(40, 40, 1, 4)
+        sc.set_background((0.7, 0.8, 1.0), sky_gradient=True, defocus_blur=False)
+        sc.camera(cam, (0.05, 0.02, -0.03), (0, 1, 0), 38.0)
+        build(sc, sc.lambertian(sc.solid_color((0.6, 0.5, 0.4))))
+        osc = rtcheck.OracleScene(sc)
+        for y in range(40):
+            for x in range(40):
+                _, q = rtcheck.oracle_trace_sample(osc, 5, x, y, 0, max_queries=3)
+                if len(q) < 2 or q[0, 7] == 0.0:
+                    continue
+                o, d, t = q[0, 0:3].astype(np.float64), q[0, 3:6].astype(np.float64), float(q[0, 6])
+                p = o + t * d
+                assert np.abs(q[1, 0:3] - p).max() < 1e-5 * max(1.0, np.abs(p).max()), (name, "hit point", x, y)
+                n = np.asarray(normal_at(p), float)
+                n = n / np.linalg.norm(n)
+                if np.dot(n, d) > 0:
+                    n = -n  # against the incoming ray
+                dev = abs(np.linalg.norm(q[1, 3:6].astype(np.float64) - n) - 1.0)
+                assert dev < 2e-5, (name, "normal", x, y, dev)
+                total += 1
+    assert total >= min_hits, (name, total)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_rect_normals(rtmi, rtcheck, axis):
+    nrm = ((0, 0, 1), (0, 1, 0), (1, 0, 0))[axis]  # object.cuh:117, 154, 187: the +axis normal, then set_face_normal
+    build = lambda sc, m: (sc.xy_rect, sc.xz_rect, sc.yz_rect)[axis](-0.9, 1.0, -0.7, 0.8, 0.1, m)
+    cams = [tuple(4.0 * np.array(v)) for v in ((0.6, 0.5, 0.7), (-0.5, -0.6, -0.7), (0.7, -0.4, 0.5))]
+    _normal_check(rtmi, rtcheck, build, lambda p: nrm, cams, f"rect axis {axis}")
+
+
+@pytest.mark.parametrize("case", [((0, 0, 1), 0.0, (0, 0, 0)), ((1, 2, 3), 37.0, (-0.2, 0.1, 0.1)), ((1, 0, 0), 90.0, (0.1, -0.1, 0.2))])
+def test_cylinder_normals(rtmi, rtcheck, case):
+    axis, deg, off = case
+    Rm = _rodrigues(axis, deg)
+    build = lambda sc, m: sc.cylinder(0.6, -0.8, 0.7, m, rotate=(axis, deg), translate=off)
+
+    def normal_at(p):  # object.cuh:276-281: (x, y, 0) in object space, carried to world space by the rotation
+        q = (np.asarray(p) - np.asarray(off)) @ Rm
+        return Rm @ np.array([q[0], q[1], 0.0])
+    cams = [(2.5, 1.5, 3.0), (-3.0, -1.0, 2.0), (0.3, 3.5, 0.8), (0.2, -0.4, 4.0)]  # outside views and down the open tube
+    _normal_check(rtmi, rtcheck, build, normal_at, cams, f"cylinder {case}")
+
+
+def test_triangle_normals(rtmi, rtcheck):
+    v = np.array([[-0.9, -0.6, 0.1], [1.0, -0.4, -0.3], [0.1, 0.9, 0.4]])
+    n = np.cross(v[1] - v[0], v[2] - v[0])
+    build = lambda sc, m: sc.triangle(tuple(v[0]), tuple(v[1]), tuple(v[2]), m)
+    _normal_check(rtmi, rtcheck, build, lambda p: n, [(1.0, 0.8, 3.0), (-0.5, -1.0, -3.0), (2.0, 0.2, 1.5)], "triangle", min_hits=200)
+
+
+def test_sphere_normals_inside_and_out(rtmi, rtcheck):
+    c, r = np.array([0.1, -0.1, 0.0]), 0.8
+    build = lambda sc, m: sc.sphere(tuple(c), r, m)
+    _normal_check(rtmi, rtcheck, build, lambda p: np.asarray(p) - c, [(2.0, 1.0, 2.5), (0.15, -0.05, 0.1)], "sphere")
