@@ -174,6 +174,7 @@ def main():
     # the communicator's own stream; a frame is placed on rank 0 one step after it was rendered, the last one before the
     # closing barrier of whatever region the steps are in).  --no-overlap: one buffer, every step waits for its gather.
     overlap = world > 1 and not args.no_overlap
+    serial = [not overlap]  # (set by the priming step if the overlapped form fails on this installation)
     locals_ = [rdist.alloc_local(scene, base, world, device) for _ in range(2 if overlap else 1)]
     local = locals_[0]
     full = torch.empty((scene.height, scene.width, 3), dtype=torch.float32, device=device) if rank == 0 else None
@@ -199,7 +200,7 @@ def main():
         if events is not None:
             e1.record()
             events.append((e0, e1))
-        if not overlap:
+        if serial[0]:
             return rdist.gather_framebuffer(buf, scene, base, rank, world, out=full, via_host=via_host)
         started = rdist.gather_begin(buf, rank, world, via_host=via_host, slot=(n_steps[0] - 1) % 2)
         img = finish_gather()  # the previous frame: its buffer is free again once this returns
@@ -215,8 +216,16 @@ def main():
     # occupancy query, and the communicator's first collective.  It is the same launch as a step, so that
     # every render_kernel row of a `rocprofv3 --stats` summary of this command is one step's launch.
     with stdout_to_stderr():
-        step()
-        finish_gather()
+        try:
+            step()
+            finish_gather()
+        except Exception as e:  # (every rank runs the same calls: a refusal of the asynchronous gather is common to all of them)
+            if serial[0]:
+                raise
+            print(f"rank {rank}: overlapped gather failed ({e!r}); one gather per step from here on", file=sys.stderr, flush=True)
+            serial[0] = True
+            in_flight.clear()
+            step()
         if world > 1:
             dist.barrier()
     for _ in range(args.warmup):
@@ -227,7 +236,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img = step(events)
-    if overlap:
+    if not serial[0]:
         img = finish_gather()  # the last frame's gather and placement belong to the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -262,7 +271,7 @@ def main():
                         f"{scene.width}x{scene.height}, {scene.spp} spp, depth {scene.max_depth}",
             "sharding": f"row tiles of {args.tile_rows} rows dealt out to {world} rank(s) (rt_opts.tile_rotate = {base.tile_rotate}), "
                         f"one gather to rank 0 per frame ({args.backend}"
-                        + (", overlapping the next frame's render)" if overlap else ")"),
+                        + (", overlapping the next frame's render)" if not serial[0] else ")"),
             "spp_chunk": chunk,
             "kernel_variant": args.variant,
             "render_seed": args.seed,
