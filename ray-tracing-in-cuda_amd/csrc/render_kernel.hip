@@ -58,7 +58,9 @@
 // With every section at priority 0 the frame takes 131.5 ms; query + hit record + pixel accumulation at 2, scatter step /
 // camera ray at 1, refill and rejection loop at 0: 127.2 ms (-3.3 %).  Measured: walk alone at 1 / 2 / 3: 129.7 / 130.1 /
 // 129.5; query set-up + walk at 1: 128.6; + hit record and accumulation: 127.6; + scatter at 1: 127.4; the rejection loop
-// or the refill raised instead: 131.6 / 128.8; the walk LOWERED: 133.4.
+// or the refill raised instead: 131.6 / 128.8; the walk LOWERED: 133.4.  Re-measured on round 3's kernel (121.8 ms): the refill at
+// 1 -- level with the scatter step -- 121.0 (-0.6 %, three alternations on one box), at 2: 122.2; the rejection loop at 1: 123.5;
+// the walk at 3 and / or the hit record at 3 on top of the refill at 1: 120.3 - 121.0, inside the noise of 121.0.
 #ifndef RT_PRIO_Q
 #define RT_PRIO_Q 2  /* query set-up: prefix spheres, grid entry */
 #endif
@@ -69,7 +71,7 @@
 #define RT_PRIO_H 2  /* from the end of the walk to the refill: other primitives, hit record, pixel accumulation */
 #endif
 #ifndef RT_PRIO_F
-#define RT_PRIO_F 0  /* refill (seeding, jitter) */
+#define RT_PRIO_F 1  /* refill (seeding, jitter) */
 #endif
 #ifndef RT_PRIO_R
 #define RT_PRIO_R 0  /* rejection loop */
