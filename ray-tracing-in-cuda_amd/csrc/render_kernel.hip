@@ -60,15 +60,16 @@
 // 129.5; query set-up + walk at 1: 128.6; + hit record and accumulation: 127.6; + scatter at 1: 127.4; the rejection loop
 // or the refill raised instead: 131.6 / 128.8; the walk LOWERED: 133.4.  Re-measured on round 3's kernel (121.8 ms): the refill at
 // 1 -- level with the scatter step -- 121.0 (-0.6 %, three alternations on one box), at 2: 122.2; the rejection loop at 1: 123.5;
-// the walk at 3 and / or the hit record at 3 on top of the refill at 1: 120.3 - 121.0, inside the noise of 121.0.
+// the walk and the hit record at 3 on top of that: 120.5 against 120.9 (means of five alternations; the walk alone at 3: 120.8, the
+// query set-up at 3 as well: 121.05, at 1: 121.1, the scatter step at 2: 120.6).
 #ifndef RT_PRIO_Q
 #define RT_PRIO_Q 2  /* query set-up: prefix spheres, grid entry */
 #endif
 #ifndef RT_PRIO_W
-#define RT_PRIO_W 2  /* grid walk */
+#define RT_PRIO_W 3  /* grid walk */
 #endif
 #ifndef RT_PRIO_H
-#define RT_PRIO_H 2  /* from the end of the walk to the refill: other primitives, hit record, pixel accumulation */
+#define RT_PRIO_H 3  /* from the end of the walk to the refill: other primitives, hit record, pixel accumulation */
 #endif
 #ifndef RT_PRIO_F
 #define RT_PRIO_F 1  /* refill (seeding, jitter) */
