@@ -36,13 +36,16 @@ def test_random_schedules_equal_the_checker(rtmi, rtcheck, scenes_dir, fuzz_seed
         tf = int(rng.integers(0, stride))
         # (the compact-table variants for the sphere-only scene, the wide-table ones for the others)
         variant = int(rng.choice([0, 0, 0, 1, 2, 6, 64, 32, 40, 128] if kind == 0 else [0, 0, 0, 36, 44, 16, 64, 32, 128]))
+        # (how the tiles are dealt out to the shards, rt_opts.tile_rotate: drawn from a generator of its own, so that the cases
+        #  of the earlier rounds keep their other draws)
+        deal = int(np.random.default_rng(1000 * fuzz_seed + case).integers(0, 3))
         o = rtmi.Opts(seed=int(rng.integers(0, 2**31)), sample_first=first, sample_count=count, spp_chunk=chunk,
-                      tile_rows=tile_rows, tile_first=tf, tile_stride=stride, variant=variant)
+                      tile_rows=tile_rows, tile_first=tf, tile_stride=stride, tile_rotate=deal, variant=variant)
         rows = sc.shard_global_rows(o)
         img = sc.render(o)
         ref, _ = rtcheck.oracle_render(sc, seed=o.seed, sample_first=first, sample_count=count)
         what = (f"case {case}: {w}x{h} spp {spp} scene {kind} samples [{first},+{count}) chunk {chunk} "
-                f"tile_rows {tile_rows} shard {tf}/{stride} variant {variant}")
+                f"tile_rows {tile_rows} shard {tf}/{stride} deal {deal} variant {variant}")
         assert img.shape[0] == len(rows), what
         if len(rows):
             assert np.array_equal(img, ref[rows]), what
