@@ -27,15 +27,17 @@ for case in range(n_cases):
     chunk = int(rng.choice([0, 0, 1, 3, 7, 8, 16, 17, 32, 50, 64, 128]))
     tile_rows = int(rng.choice([1, 3, 8, 8, 16]))
     stride = int(rng.integers(1, 6)); tf = int(rng.integers(0, stride))
-    variant = int(rng.choice([0, 0, 0, 1, 64, 32, 40]))
+    # (the compact-table variants for the sphere-only scene, the wide-table ones for the others: tests/test_gpu_fuzz.py)
+    variant = int(rng.choice([0, 0, 0, 1, 2, 6, 64, 32, 40, 128] if kind == 0 else [0, 0, 0, 36, 44, 16, 64, 32, 128]))
+    deal = int(rng.integers(0, 3))  # rt_opts.tile_rotate
     o = rtmi.Opts(seed=int(rng.integers(0, 2**31)), sample_first=first, sample_count=count, spp_chunk=chunk,
-                  tile_rows=tile_rows, tile_first=tf, tile_stride=stride, variant=variant)
+                  tile_rows=tile_rows, tile_first=tf, tile_stride=stride, tile_rotate=deal, variant=variant)
     rows = sc.shard_global_rows(o)
     img = sc.render(o)
     ref, _ = rtcheck.oracle_render(sc, seed=o.seed, sample_first=first, sample_count=count)
     ok = img.shape[0] == len(rows) and (len(rows) == 0 or np.array_equal(img, ref[rows]))
     if not ok:
         bad += 1
-        print(f"MISMATCH case {case}: {w}x{h} spp {spp} kind {kind} first {first} count {count} chunk {chunk} tile_rows {tile_rows} shard {tf}/{stride} variant {variant}", flush=True)
+        print(f"MISMATCH case {case}: {w}x{h} spp {spp} kind {kind} first {first} count {count} chunk {chunk} tile_rows {tile_rows} shard {tf}/{stride} deal {deal} variant {variant}", flush=True)
 print(f"{n_cases} random cases, {bad} mismatches", flush=True)
 sys.exit(1 if bad else 0)
