@@ -281,7 +281,7 @@ typedef struct rt_opts {
     int32_t tile_rotate;
     /* samples per work item (one wave renders an 8x8 tile x spp_chunk samples at a time).
      * Scheduling only: the per-pixel sum is exact (64-bit fixed point, 2^-24), so the
-     * framebuffer does not depend on it.  0 -> 128 (less for small frames).          */
+     * framebuffer does not depend on it.  0 -> 256 (less for small frames).          */
     int32_t spp_chunk;
     int32_t sample_first; /* render samples [sample_first, sample_first+count) */
     int32_t sample_count; /* 0 -> scene spp                                    */

@@ -1023,7 +1023,9 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         // triangle mesh), and a wave's share evens out only over several items (20 000 triangles at 1280 x 720 x 16: 31.2 ms
         // with 4 items of 8 samples per wave, 24.6 with 8 of 4; 20 000 spheres 10.1 either way)
         const long long want_items = 8LL * 256 * RT_WAVES_PER_SIMD * 4;
-        spp_chunk = 128;
+        // (256 for launches that have the items: with the graded tail below the whole 1080p x 1024 spp frame takes 119.3 ms with 128-
+        //  or 256-sample items (512: 120.0), and every item flushes a 1.5 KB tile accumulator once: half the items, half that traffic)
+        spp_chunk = 256;
         while (spp_chunk > 4 && tiles * ((sample_count + spp_chunk - 1) / spp_chunk) < want_items) spp_chunk /= 2;
     }
     if (spp_chunk > sample_count) spp_chunk = sample_count;
@@ -1032,14 +1034,18 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // wall time (seven waves share a SIMD) and an item over glass and dense spheres several times the average,
     // so the runs of shorter items have to last long enough for the other waves to have something to do
     // meanwhile.  How many big chunks are given up follows from r = resident waves / tiles: a whole 1080p
-    // frame (r = 0.22) gives up two of sixteen, a 1/8 row shard (r = 1.8) thirteen, of which 13
-    // quarter chunks are cut into 4-sample items.  Short items cost little since stragglers no longer
+    // frame (r = 0.22) gives up two of four 256-sample chunks, a 1/8 row shard (r = 1.8) thirteen of sixteen 64-sample ones; of
+    // the medium chunks that many again are cut into small ones.  Short items cost little since stragglers no longer
     // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
     // (knob(): measurement knobs of the default build, constants in a product build)
     static const int tail_mode = (int)knob("RTMI_TAIL_MODE", 1);  // 0 = one run of equal chunks
     // (round 2: 4 / 6 / 8 / 12 -> a 1/4 shard 66.0 / 63.8 / 63.2 / 61.8 ms.  Round 3, four times as many items, RTIOW 1080p x 1024 spp
     //  (tools/gpu_tail_sweep.py): 5 / 6 / 7 / 8 / 12 -> rank 0's 1/8 shard 16.70 / 16.32 / 16.34 / 16.41 / 16.53 ms, a 1/4 shard 31.62 /
     //  31.21 / 31.42 / 31.49 / 31.63, the whole frame within 0.2 %; at 4 and below the last big items outlast the short ones: 17.7 ms)
+    //  Round 3's last session (tools/gpu_tail_sweep.py; whole frame / a 1/2 / a 1/4 / rank 0's and rank 3's 1/8 shard, ms): with a run of
+    //  small items for the big launches too (below) 120.35 / 61.60 / 31.06 / 16.13 / 15.49 -> 119.52 / 60.45 / 31.05 / 16.15 / 15.51.
+    //  Rounding the number of big chunks given up DOWN as well (one for a whole 1080p frame instead of two) brings 119.25 / 60.15 / 31.00 /
+    //  16.12 / 15.48, but sits next to the cliff (factor 5 takes a 1/4 shard to 32.06 ms): it stays rounded up.)
     static const double tail_factor = knob("RTMI_TAIL_FACTOR", 7.0);
     static const int tail_div = std::max(2, (int)knob("RTMI_TAIL_DIV", 4));  // big : medium item length
     static const int orphan_env = (int)knob("RTMI_ORPHAN_MAX", -1);
@@ -1057,7 +1063,11 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
             q_med = std::max(4, spp_chunk / tail_div);
             q_small = std::max(4, q_med / 4);
             int small_samples = 0;
-            if (r >= 0.5 && q_small < q_med)  // few tiles per wave: a run of small items as well
+            // a run of small items behind the medium ones: for launches of few tiles per wave, and (round 3's end) for every launch whose
+            // small items are still 16 samples long (the whole 1080p x 1024 spp frame 120.35 -> 119.5 ms, a 1/2 shard 61.6 -> 60.5; with
+            // 4-sample items at r = 0.5 the DNA frame goes from 6.6 to 7.7 ms: 400 000 items for 6 ms of work)
+            static const double small_r = knob("RTMI_SMALL_R", 0.5);
+            if ((r >= small_r || q_small >= 16) && q_small < q_med)
                 small_samples = std::min(rest - q_med, std::max(1, (int)std::ceil(tail_factor * r)) * q_med);
             if (small_samples < 0) small_samples = 0;
             n_med = (rest - small_samples) / q_med;  // whole medium chunks; the small run takes what is left

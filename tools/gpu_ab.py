@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     rtmi = load_package()
     spp, variant = int(sys.argv[2]), int(sys.argv[3])
     sc = rtmi.Scene.rtiow(7, 1920, 1080, spp, 50)
-    o = rtmi.Opts(seed=2023, variant=variant)
+    o = rtmi.Opts(seed=2023, variant=variant, spp_chunk=int(os.environ.get("RTMI_AB_CHUNK", "0")))  # (0: the library's choice)
     import zlib
     crc = zlib.crc32(sc.render(o).tobytes())
     ms = []

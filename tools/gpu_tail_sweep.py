@@ -21,7 +21,10 @@ else:
     spp = sys.argv[1] if len(sys.argv) > 1 else "1024"
     specs = (sys.argv[2] if len(sys.argv) > 2 else "12:4,8:4,6:4,4:4,3:4,2:4,6:2,6:8,4:8").split(",")
     for spec in specs:
-        f, d = spec.split(":")
+        f, d, *more = spec.split(":")
         env = dict(os.environ, RTMI_TAIL_FACTOR=f, RTMI_TAIL_DIV=d)
-        print(f"[factor {f} div {d}]", flush=True)
+        for kv in more:  # FACTOR:DIV[:NAME=VALUE ...]
+            k, v = kv.split("=")
+            env[k] = v
+        print(f"[factor {f} div {d} {' '.join(more)}]", flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), "child", spp], env=env, check=True)
