@@ -1023,8 +1023,9 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         // triangle mesh), and a wave's share evens out only over several items (20 000 triangles at 1280 x 720 x 16: 31.2 ms
         // with 4 items of 8 samples per wave, 24.6 with 8 of 4; 20 000 spheres 10.1 either way)
         const long long want_items = 8LL * 256 * RT_WAVES_PER_SIMD * 4;
-        // (256 for launches that have the items: with the graded tail below the whole 1080p x 1024 spp frame takes 119.3 ms with 128-
-        //  or 256-sample items (512: 120.0), and every item flushes a 1.5 KB tile accumulator once: half the items, half that traffic)
+        // (256 for launches that have the items: with the graded tail below the whole 1080p x 1024 spp frame takes the same 119.3 -
+        //  119.7 ms with 128- or 256-sample items (512: 120.0); the tail's medium and small items keep the item count -- 16 per tile
+        //  against 14 -- and with it the accumulator flushes where they were: 1.28 GB of HBM writes per frame, PMC)
         spp_chunk = 256;
         while (spp_chunk > 4 && tiles * ((sample_count + spp_chunk - 1) / spp_chunk) < want_items) spp_chunk /= 2;
     }
