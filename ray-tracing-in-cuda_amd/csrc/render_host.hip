@@ -1035,7 +1035,7 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     // wall time (seven waves share a SIMD) and an item over glass and dense spheres several times the average,
     // so the runs of shorter items have to last long enough for the other waves to have something to do
     // meanwhile.  How many big chunks are given up follows from r = resident waves / tiles: a whole 1080p
-    // frame (r = 0.22) gives up two of four 256-sample chunks, a 1/8 row shard (r = 1.8) thirteen of sixteen 64-sample ones; of
+    // frame (r = 0.22) gives up one of four 256-sample chunks, a 1/8 row shard (r = 1.8) twelve of sixteen 64-sample ones; of
     // the medium chunks that many again are cut into small ones.  Short items cost little since stragglers no longer
     // block a wave's next item (chunk sizes 16..128 measure within 1.5 % on the whole frame).
     // (knob(): measurement knobs of the default build, constants in a product build)
@@ -1045,8 +1045,9 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
     //  31.21 / 31.42 / 31.49 / 31.63, the whole frame within 0.2 %; at 4 and below the last big items outlast the short ones: 17.7 ms)
     //  Round 3's last session (tools/gpu_tail_sweep.py; whole frame / a 1/2 / a 1/4 / rank 0's and rank 3's 1/8 shard, ms): with a run of
     //  small items for the big launches too (below) 120.35 / 61.60 / 31.06 / 16.13 / 15.49 -> 119.52 / 60.45 / 31.05 / 16.15 / 15.51.
-    //  Rounding the number of big chunks given up DOWN as well (one for a whole 1080p frame instead of two) brings 119.25 / 60.15 / 31.00 /
-    //  16.12 / 15.48, but sits next to the cliff (factor 5 takes a 1/4 shard to 32.06 ms): it stays rounded up.)
+    //  The number of big chunks given up rounded DOWN as well (one for a whole 1080p frame instead of two; 3 / 6 / 12 for the shards): 119.72 /
+    //  60.98 / 31.09 / 16.15 / 15.54 -> 119.42 / 60.72 / 30.97 / 16.15 / 15.48, the DNA frame 6.61 -> 6.52, 20 000 triangles 26.8 -> 25.5 ms;
+    //  the cliff (factor 5 rounded down: four chunks for a 1/4 shard, 32.06 ms) is two chunks away.)
     static const double tail_factor = knob("RTMI_TAIL_FACTOR", 7.0);
     static const int tail_div = std::max(2, (int)knob("RTMI_TAIL_DIV", 4));  // big : medium item length
     static const int orphan_env = (int)knob("RTMI_ORPHAN_MAX", -1);
@@ -1058,7 +1059,8 @@ static int render_impl(const rt_scene *sc, const rt_opts *o, void *d_rgb_sum, vo
         const int rem = sample_count - n_big * spp_chunk;
         int rest = rem;  // samples after the big chunks
         if (tail_mode > 0 && spp_chunk >= 16 && n_big >= 1) {
-            const int n_split = std::min(n_big, std::max(1, (int)std::ceil(tail_factor * r)));  // big chunks given up
+            static const int tail_floor = (int)knob("RTMI_TAIL_FLOOR", 1);  // (0: round up, as until the end of round 3)
+            const int n_split = std::min(n_big, std::max(1, tail_floor ? (int)std::floor(tail_factor * r) : (int)std::ceil(tail_factor * r)));  // big chunks given up
             n_big -= n_split;
             rest += n_split * spp_chunk;
             q_med = std::max(4, spp_chunk / tail_div);
